@@ -1,0 +1,867 @@
+// oflk.hip -- host side of liboflk.so: C ABI (include/oflk.h), plans, launch
+// orchestration.  Device code lives in oflk_kernels.hpp.
+//
+// Build (see optical-flow-fpga_amd/csrc/Makefile):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ...
+//
+// There is deliberately no CPU path in this library: with no usable GPU every
+// compute entry point returns OFLK_ERR_NO_DEVICE.
+#include "oflk_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/oflk.h"
+
+#define OFLK_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+using namespace oflk;
+
+thread_local std::string t_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    t_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(OFLK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+int g_device = 0;
+
+int ensure_device(int dev)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(OFLK_ERR_NO_DEVICE,
+                    "no usable HIP device (hipGetDeviceCount: %s, count %d); liboflk has no CPU path",
+                    hipGetErrorString(e), n);
+    }
+    if (dev < 0 || dev >= n) return fail(OFLK_ERR_INVALID, "device %d out of range [0,%d)", dev, n);
+    HIP_TRY(hipSetDevice(dev));
+    return OFLK_OK;
+}
+
+// scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, int(4*sigma+0.5)).  For the
+// reference's sigma (2.0 = 1/scale_factor, lucas_kanade_pyramidal.py:46) the
+// table is SciPy's own output (NumPy's exp differs from libm's in the last ulp
+// for some taps); other sigmas use libm and NumPy's pairwise normalisation order.
+const double kSigma2[9] = {0x1.98862a07ae7b4p-3,  0x1.68856f9ab1982p-3,  0x1.ef9093fc46e5ap-4,
+                           0x1.0941b71ceef37p-4,  0x1.ba4d4125ffd2ap-6,  0x1.1f30504e20207p-7,
+                           0x1.227362b5fc92dp-9,  0x1.c98b8c5d0dda5p-12, 0x1.18aad19e4159bp-14};
+
+double np_pairwise_f64(const double *a, size_t n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (size_t i = 0; i < n; i++) r += a[i];
+        return r;
+    } else if (n <= 128) {
+        double r[8];
+        size_t i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_f64(a, n2) + np_pairwise_f64(a + n2, n - n2);
+}
+
+int make_gauss(double sigma, GaussW *g)
+{
+    if (!(sigma > 0.0)) return fail(OFLK_ERR_INVALID, "sigma must be positive");
+    int radius = (int)(4.0 * sigma + 0.5);
+    if (radius > kMaxRadius)
+        return fail(OFLK_ERR_UNSUPPORTED, "gaussian radius %d > %d (scale_factor too small)", radius,
+                    kMaxRadius);
+    g->radius = radius;
+    if (sigma == 2.0) {
+        for (int k = 0; k <= 8; k++) g->w[k] = kSigma2[k];
+        return OFLK_OK;
+    }
+    double phi[2 * kMaxRadius + 1];
+    double c = -0.5 / (sigma * sigma);
+    for (int i = -radius; i <= radius; i++) phi[i + radius] = std::exp(c * (double)(i * i));
+    double s = 0.0 + np_pairwise_f64(phi, (size_t)(2 * radius + 1));
+    for (int k = 0; k <= radius; k++) g->w[k] = phi[radius + k] / s;
+    return OFLK_OK;
+}
+
+Linspace make_linspace(int S, int T)
+{
+    Linspace l;
+    l.T = T;
+    l.last = (double)(S - 1);
+    l.step = T > 1 ? (double)(S - 1) / (double)(T - 1) : 0.0;
+    return l;
+}
+
+int level_dims(int H, int W, int levels, double scale, int *dims)
+{
+    if (H < 1 || W < 1) return fail(OFLK_ERR_INVALID, "H and W must be >= 1 (got %d x %d)", H, W);
+    if (levels < 1 || levels > OFLK_MAX_LEVELS)
+        return fail(OFLK_ERR_INVALID, "levels must be in [1,%d] (got %d)", OFLK_MAX_LEVELS, levels);
+    if (!(scale > 0.0 && scale <= 1.0))
+        return fail(OFLK_ERR_INVALID, "scale_factor must be in (0,1] (got %g)", scale);
+    int h = H, w = W;
+    for (int l = levels - 1; l >= 0; l--) {
+        if (h < 1 || w < 1)
+            return fail(OFLK_ERR_INVALID, "pyramid level %d of %dx%d would be empty", l, W, H);
+        dims[2 * l] = h;
+        dims[2 * l + 1] = w;
+        h = (int)((double)h * scale);  // int(height * scale_factor), lucas_kanade_pyramidal.py:51
+        w = (int)((double)w * scale);
+    }
+    return OFLK_OK;
+}
+
+int window_hw(int window_size, int *hw)
+{
+    if (window_size < 1) return fail(OFLK_ERR_INVALID, "window_size must be >= 1");
+    int h = window_size / 2;  // even sizes round down, lucas_kanade_core.py:104
+    if (h < 1 || h > 3)
+        return fail(OFLK_ERR_UNSUPPORTED,
+                    "window_size %d not built (kernels exist for 3x3, 5x5, 7x7 windows)", window_size);
+    *hw = h;
+    return OFLK_OK;
+}
+
+// ---- kernel classes for the per-kernel event timing --------------------------
+enum KClass { KC_LK_SINGLE = 0, KC_LK_ITER, KC_LK_ITER_FINEST, KC_FINALIZE, KC_BLUR, KC_RESAMPLE,
+              KC_UPSAMPLE, KC_EXPORT, KC_MEMSET, KC_COUNT };
+const char *kClassNames[KC_COUNT] = {"lk_single", "lk_iter", "lk_iter_finest", "finalize", "blur",
+                                     "pyr_resample", "flow_upsample", "export_fixup", "memset"};
+
+}  // namespace
+
+struct oflk_plan {
+    int device = 0;
+    int B = 0, H = 0, W = 0, L = 0, win = 0, hw = 0, K = 0;
+    int dims[2 * OFLK_MAX_LEVELS] = {0};
+    size_t ws_bytes = 0;
+    // workspace
+    float *pyr[OFLK_MAX_LEVELS] = {nullptr};      // l < L-1: [2B][h][w] (prev then curr)
+    float *tmpA = nullptr, *tmpB = nullptr;       // blur temporaries [2B][H][W]
+    // per level one block: [slot 0..1][u, v][B][h][w]; the finest level owns one
+    // slot only (its other slot is the caller's output buffers)
+    float *flow[OFLK_MAX_LEVELS] = {nullptr};
+    double *partial = nullptr;                    // [B][nblk_max][2]
+    int *state = nullptr;                         // sel[L][B], done[L][B], iters_run[B][L]
+    float *log = nullptr;                         // [B][L][K][2]
+    GaussW gauss;
+    // profiling
+    bool prof = false;
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double acc_ms[KC_COUNT] = {0};
+    long acc_n[KC_COUNT] = {0};
+
+    size_t npix(int l) const { return (size_t)dims[2 * l] * (size_t)dims[2 * l + 1]; }
+    float *fu(int l, int slot) const { return flow[l] + (size_t)(2 * slot) * B * npix(l); }
+    float *fv(int l, int slot) const { return flow[l] + (size_t)(2 * slot + 1) * B * npix(l); }
+    int *sel(int l) const { return state + (size_t)l * B; }
+    int *done(int l) const { return state + (size_t)(L + l) * B; }
+    int *iters_run() const { return state + (size_t)2 * L * B; }
+    size_t state_ints() const { return (size_t)3 * L * B; }
+};
+
+namespace {
+
+struct Prof {
+    oflk_plan *p;
+    hipStream_t s;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(oflk_plan *p_, hipStream_t s_, int cls_) : p(p_), s(s_), cls(cls_)
+    {
+        if (!p || !p->prof) return;
+        if (p->pool.empty()) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+        } else {
+            a = p->pool.back().first;
+            b = p->pool.back().second;
+            p->pool.pop_back();
+        }
+        (void)hipEventRecord(a, s);
+    }
+    ~Prof()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, s);
+        p->pending.push_back({a, b, cls});
+    }
+};
+
+template <int MODE>
+int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a, int B)
+{
+    dim3 grid((a.W + kTX - 1) / kTX, (a.H + kTY - 1) / kTY, B);
+    dim3 block(kLkThreads);
+    Prof pr(plan, s, cls);
+    switch (hw) {
+        case 1: hipLaunchKernelGGL((k_lk<1, MODE>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_lk<2, MODE>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_lk<3, MODE>), grid, block, 0, s, a); break;
+        default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
+    }
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
+inline dim3 grid2d(int W, int H, int n) { return dim3((W + 63) / 64, (H + 3) / 4, n); }
+
+// gaussian blur + linspace resample of `nimg` images: in [nimg][h][w] -> out [nimg][ho][wo]
+int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const float *in, float *out,
+                    float *tmpA, float *tmpB, int nimg, int h, int w, int ho, int wo)
+{
+    {
+        Prof pr(plan, s, KC_BLUR);
+        hipLaunchKernelGGL((k_blur<0>), grid2d(w, h, nimg), dim3(256), 0, s, in, tmpA, h, w, gauss);
+        hipLaunchKernelGGL((k_blur<1>), grid2d(w, h, nimg), dim3(256), 0, s, (const float *)tmpA, tmpB, h,
+                           w, gauss);
+    }
+    HIP_TRY(hipGetLastError());
+    ResampleArgs r{};
+    r.in[0] = tmpB;
+    r.out[0] = out;
+    r.sel = nullptr;
+    r.in_sel_stride = 0;
+    r.H = h; r.W = w; r.Ho = ho; r.Wo = wo;
+    r.ly = make_linspace(h, ho);
+    r.lx = make_linspace(w, wo);
+    r.nplanes = 1;
+    r.apply_scale = 0;
+    {
+        Prof pr(plan, s, KC_RESAMPLE);
+        hipLaunchKernelGGL(k_resample, grid2d(wo, ho, nimg), dim3(256), 0, s, r);
+    }
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
+template <typename T>
+int dmalloc(T **p, size_t n, size_t *total)
+{
+    size_t bytes = std::max<size_t>(n * sizeof(T), 256);
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(OFLK_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    *total += bytes;
+    return OFLK_OK;
+}
+
+void plan_free(oflk_plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (int l = 0; l < OFLK_MAX_LEVELS; l++) {
+        if (p->pyr[l]) (void)hipFree(p->pyr[l]);
+        if (p->flow[l]) (void)hipFree(p->flow[l]);
+    }
+    if (p->tmpA) (void)hipFree(p->tmpA);
+    if (p->tmpB) (void)hipFree(p->tmpB);
+    if (p->partial) (void)hipFree(p->partial);
+    if (p->state) (void)hipFree(p->state);
+    if (p->log) (void)hipFree(p->log);
+    for (auto &e : p->pending) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (auto &e : p->pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete p;
+}
+
+}  // namespace
+
+// =============================================================================
+// library
+// =============================================================================
+OFLK_API const char *oflk_version(void) { return "oflk 0.1.0 (gfx950)"; }
+
+OFLK_API int oflk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+OFLK_API const char *oflk_last_error(void) { return t_err.c_str(); }
+
+OFLK_API int oflk_set_device(int device)
+{
+    int rc = ensure_device(device);
+    if (rc == OFLK_OK) g_device = device;
+    return rc;
+}
+
+OFLK_API int oflk_pyramid_level_dims(int H, int W, int levels, double scale_factor, int *dims_out)
+{
+    if (!dims_out) return fail(OFLK_ERR_INVALID, "dims_out is NULL");
+    return level_dims(H, W, levels, scale_factor, dims_out);
+}
+
+// =============================================================================
+// plan API
+// =============================================================================
+OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, int levels,
+                              int window_size, int iters)
+{
+    if (!out) return fail(OFLK_ERR_INVALID, "plan pointer is NULL");
+    *out = nullptr;
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    if (iters < 0) return fail(OFLK_ERR_INVALID, "iters must be >= 0");
+    if ((size_t)H * (size_t)W > (size_t)0x7fffffff)
+        return fail(OFLK_ERR_UNSUPPORTED, "frames above 2^31 pixels are not supported");
+    int hw = 0;
+    int rc = window_hw(window_size, &hw);
+    if (rc) return rc;
+    int dims[2 * OFLK_MAX_LEVELS];
+    rc = level_dims(H, W, levels, 0.5, dims);
+    if (rc) return rc;
+    rc = ensure_device(device);
+    if (rc) return rc;
+
+    oflk_plan *p = new oflk_plan();
+    p->device = device;
+    p->B = B; p->H = H; p->W = W; p->L = levels; p->win = window_size; p->hw = hw; p->K = iters;
+    std::memcpy(p->dims, dims, sizeof(int) * 2 * levels);
+    rc = make_gauss(2.0, &p->gauss);  // sigma = 1/scale_factor, scale_factor = 0.5 (:24, :46)
+    const size_t N = (size_t)H * W;
+    if (!rc && levels > 1) {
+        rc = dmalloc(&p->tmpA, 2 * (size_t)B * N, &p->ws_bytes);
+        if (!rc) rc = dmalloc(&p->tmpB, 2 * (size_t)B * N, &p->ws_bytes);
+    }
+    size_t nblk_max = 1;
+    for (int l = 0; l < levels && !rc; l++) {
+        size_t n = (size_t)dims[2 * l] * dims[2 * l + 1];
+        if (l < levels - 1) rc = dmalloc(&p->pyr[l], 2 * (size_t)B * n, &p->ws_bytes);
+        // finest level: one of the ping-pong buffers is the caller's output
+        int nb = (l == levels - 1) ? 1 : 2;
+        if (!rc) rc = dmalloc(&p->flow[l], (size_t)nb * 2 * B * n, &p->ws_bytes);
+        size_t nblk = (size_t)((dims[2 * l + 1] + kTX - 1) / kTX) * ((dims[2 * l] + kTY - 1) / kTY);
+        nblk_max = std::max(nblk_max, nblk);
+    }
+    if (!rc) rc = dmalloc(&p->partial, (size_t)B * nblk_max * 2, &p->ws_bytes);
+    if (!rc) rc = dmalloc(&p->state, p->state_ints(), &p->ws_bytes);
+    if (!rc) rc = dmalloc(&p->log, (size_t)B * levels * std::max(iters, 1) * 2, &p->ws_bytes);
+    if (rc) {
+        std::string keep = t_err;
+        plan_free(p);
+        t_err = keep;
+        return rc;
+    }
+    *out = p;
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_plan_destroy(oflk_plan *plan)
+{
+    plan_free(plan);
+    return OFLK_OK;
+}
+
+OFLK_API size_t oflk_plan_workspace_bytes(const oflk_plan *plan) { return plan ? plan->ws_bytes : 0; }
+
+OFLK_API int oflk_plan_single_scale(oflk_plan *p, const float *d_prev, const float *d_curr,
+                                    float *d_u, float *d_v, void *stream)
+{
+    if (!p || !d_prev || !d_curr || !d_u || !d_v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    LkArgs a{};
+    a.prev = d_prev; a.curr = d_curr;
+    a.fu[0] = d_u; a.fv[0] = d_v;
+    a.H = p->H; a.W = p->W;
+    return launch_lk<MODE_SINGLE>(p, (hipStream_t)stream, KC_LK_SINGLE, p->hw, a, p->B);
+}
+
+OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float *d_curr, float *d_u,
+                                 float *d_v, void *stream)
+{
+    if (!p || !d_prev || !d_curr || !d_u || !d_v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int B = p->B, L = p->L, K = p->K;
+    int rc;
+
+    // ---- pyramids (lucas_kanade_pyramidal.py:173-174), fine -> coarse ---------
+    for (int l = L - 2; l >= 0; l--) {
+        int h = p->dims[2 * (l + 1)], w = p->dims[2 * (l + 1) + 1];
+        int ho = p->dims[2 * l], wo = p->dims[2 * l + 1];
+        size_t no = (size_t)ho * wo;
+        if (l == L - 2) {
+            // the finest level is the caller's frames (image.copy() at :40 is a no-op here)
+            rc = launch_pyr_down(p, p->gauss, s, d_prev, p->pyr[l], p->tmpA, p->tmpB, B, h, w, ho, wo);
+            if (rc) return rc;
+            rc = launch_pyr_down(p, p->gauss, s, d_curr, p->pyr[l] + (size_t)B * no, p->tmpA, p->tmpB, B, h, w, ho, wo);
+            if (rc) return rc;
+        } else {
+            rc = launch_pyr_down(p, p->gauss, s, p->pyr[l + 1], p->pyr[l], p->tmpA, p->tmpB, 2 * B, h, w, ho, wo);
+            if (rc) return rc;
+        }
+    }
+
+    // ---- per-call state: sel = 0, done = 0, iters_run = 0, log = 0 ------------
+    {
+        Prof pr(p, s, KC_MEMSET);
+        HIP_TRY(hipMemsetAsync(p->state, 0, p->state_ints() * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(p->log, 0, (size_t)B * L * std::max(K, 1) * 2 * sizeof(float), s));
+    }
+
+    // the caller's buffers are the ping-pong slot the final flow lands in when no
+    // level exits early at the finest level: slot K % 2
+    const int want = K & 1;
+    float *fu[OFLK_MAX_LEVELS][2], *fv[OFLK_MAX_LEVELS][2];
+    for (int l = 0; l + 1 < L; l++)
+        for (int i = 0; i < 2; i++) {
+            fu[l][i] = p->fu(l, i);
+            fv[l][i] = p->fv(l, i);
+        }
+    fu[L - 1][want] = d_u;
+    fv[L - 1][want] = d_v;
+    fu[L - 1][1 - want] = p->fu(L - 1, 0);
+    fv[L - 1][1 - want] = p->fv(L - 1, 0);
+
+    for (int l = 0; l < L; l++) {
+        const int h = p->dims[2 * l], w = p->dims[2 * l + 1];
+        const size_t n = (size_t)h * w;
+        if (l == 0) {
+            // flow = zeros at the coarsest level (:182-184)
+            Prof pr(p, s, KC_MEMSET);
+            HIP_TRY(hipMemsetAsync(fu[0][0], 0, (size_t)B * n * sizeof(float), s));
+            HIP_TRY(hipMemsetAsync(fv[0][0], 0, (size_t)B * n * sizeof(float), s));
+        } else {
+            // upsample_flow (:195-197) from whichever slot holds level l-1's result
+            const int hc = p->dims[2 * (l - 1)], wc = p->dims[2 * (l - 1) + 1];
+            ResampleArgs r{};
+            // level l-1 (never the finest) keeps both slots in one block: slot s of
+            // a plane sits s * (2*B*n_c) elements after slot 0
+            r.in[0] = fu[l - 1][0];
+            r.in[1] = fv[l - 1][0];
+            r.sel = p->sel(l - 1);
+            r.in_sel_stride = (size_t)2 * B * p->npix(l - 1);
+            r.out[0] = fu[l][0];
+            r.out[1] = fv[l][0];
+            r.scale[0] = (float)((double)w / (double)wc);  // scale_x (:123, :135)
+            r.scale[1] = (float)((double)h / (double)hc);  // scale_y (:122, :136)
+            r.H = hc; r.W = wc; r.Ho = h; r.Wo = w;
+            r.ly = make_linspace(hc, h);
+            r.lx = make_linspace(wc, w);
+            r.nplanes = 2;
+            r.apply_scale = 1;
+            Prof pr(p, s, KC_UPSAMPLE);
+            hipLaunchKernelGGL(k_resample, grid2d(w, h, B), dim3(256), 0, s, r);
+            HIP_TRY(hipGetLastError());
+        }
+        const float *lp = (l == L - 1) ? d_prev : p->pyr[l];
+        const float *lc = (l == L - 1) ? d_curr : p->pyr[l] + (size_t)B * n;
+        const int nblk = ((w + kTX - 1) / kTX) * ((h + kTY - 1) / kTY);
+        for (int k = 0; k < K; k++) {
+            LkArgs a{};
+            a.prev = lp; a.curr = lc;
+            a.fu[0] = fu[l][0]; a.fu[1] = fu[l][1];
+            a.fv[0] = fv[l][0]; a.fv[1] = fv[l][1];
+            a.partial = p->partial;
+            a.sel = p->sel(l);
+            a.done = p->done(l);
+            a.H = h; a.W = w;
+            rc = launch_lk<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, p->hw, a, B);
+            if (rc) return rc;
+            FinalizeArgs f{};
+            f.partial = p->partial;
+            f.nblk = nblk;
+            f.count = (double)n;
+            f.log = p->log;
+            f.iters_run = p->iters_run();
+            f.sel = p->sel(l);
+            f.done = p->done(l);
+            f.level = l; f.iter = k; f.L = L; f.K = std::max(K, 1);
+            Prof pr(p, s, KC_FINALIZE);
+            hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, f);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    // pairs whose finest level exited early hold their result in the internal slot
+    {
+        ExportArgs e{};
+        e.src_u = fu[L - 1][1 - want];
+        e.src_v = fv[L - 1][1 - want];
+        e.dst_u = d_u;
+        e.dst_v = d_v;
+        e.sel = p->sel(L - 1);
+        e.want = want;
+        e.plane = (size_t)p->H * p->W;
+        dim3 grid((unsigned)((e.plane + 1023) / 1024), B);
+        Prof pr(p, s, KC_EXPORT);
+        hipLaunchKernelGGL(k_export_fixup, grid, dim3(256), 0, s, e);
+        HIP_TRY(hipGetLastError());
+    }
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_plan_read_log(oflk_plan *p, float *residual_log, int *iters_run, void *stream)
+{
+    if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (residual_log)
+        HIP_TRY(hipMemcpyAsync(residual_log, p->log,
+                               (size_t)p->B * p->L * std::max(p->K, 1) * 2 * sizeof(float),
+                               hipMemcpyDeviceToHost, s));
+    if (iters_run)
+        HIP_TRY(hipMemcpyAsync(iters_run, p->iters_run(), (size_t)p->B * p->L * sizeof(int),
+                               hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_plan_set_profiling(oflk_plan *p, int enabled)
+{
+    if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
+    p->prof = enabled != 0;
+    for (auto &e : p->pending) p->pool.push_back({e.a, e.b});
+    p->pending.clear();
+    for (int i = 0; i < KC_COUNT; i++) {
+        p->acc_ms[i] = 0;
+        p->acc_n[i] = 0;
+    }
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_plan_kernel_times(oflk_plan *p, const char **names, double *total_ms,
+                                    long *launches, int max_entries)
+{
+    if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    for (auto &e : p->pending) {
+        HIP_TRY(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+        p->acc_ms[e.cls] += ms;
+        p->acc_n[e.cls] += 1;
+        p->pool.push_back({e.a, e.b});
+    }
+    p->pending.clear();
+    int n = std::min<int>(KC_COUNT, max_entries);
+    for (int i = 0; i < n; i++) {
+        if (names) names[i] = kClassNames[i];
+        if (total_ms) total_ms[i] = p->acc_ms[i];
+        if (launches) launches[i] = p->acc_n[i];
+    }
+    return n;
+}
+
+// =============================================================================
+// host-pointer entry points
+// =============================================================================
+namespace {
+
+std::mutex g_mu;
+
+struct Arena {
+    std::vector<void *> blocks;
+    ~Arena() { release(); }
+    void release()
+    {
+        for (void *b : blocks) (void)hipFree(b);
+        blocks.clear();
+    }
+    template <typename T>
+    int get(T **p, size_t n)
+    {
+        size_t tot = 0;
+        int rc = dmalloc(p, n, &tot);
+        if (!rc) blocks.push_back(*p);
+        return rc;
+    }
+};
+
+// one cached plan for repeated host calls of the same shape (the verifier runs
+// 13 patterns of one size)
+oflk_plan *g_plan = nullptr;
+float *g_io[4] = {nullptr, nullptr, nullptr, nullptr};  // device prev, curr, u, v
+size_t g_io_elems = 0;
+
+int host_plan(int B, int H, int W, int L, int win, int K, oflk_plan **out)
+{
+    if (g_plan && g_plan->device == g_device && g_plan->B == B && g_plan->H == H && g_plan->W == W &&
+        g_plan->L == L && g_plan->win == win && g_plan->K == K) {
+        *out = g_plan;
+    } else {
+        if (g_plan) {
+            plan_free(g_plan);
+            g_plan = nullptr;
+        }
+        int rc = oflk_plan_create(&g_plan, g_device, B, H, W, L, win, K);
+        if (rc) return rc;
+        *out = g_plan;
+    }
+    size_t need = (size_t)B * H * W;
+    if (need > g_io_elems) {
+        for (auto &q : g_io) {
+            if (q) (void)hipFree(q);
+            q = nullptr;
+        }
+        g_io_elems = 0;
+        size_t tot = 0;
+        for (auto &q : g_io) {
+            int rc = dmalloc(&q, need, &tot);
+            if (rc) return rc;
+        }
+        g_io_elems = need;
+    }
+    return OFLK_OK;
+}
+
+int check_hw(const void *a, const void *b, int H, int W)
+{
+    if (!a || !b) return fail(OFLK_ERR_INVALID, "NULL array argument");
+    if (H < 1 || W < 1) return fail(OFLK_ERR_INVALID, "H and W must be >= 1 (got %d x %d)", H, W);
+    if ((size_t)H * (size_t)W > (size_t)0x7fffffff)
+        return fail(OFLK_ERR_UNSUPPORTED, "frames above 2^31 pixels are not supported");
+    return OFLK_OK;
+}
+
+}  // namespace
+
+OFLK_API int oflk_single_scale_batch(const float *prev, const float *curr, int B, int H, int W,
+                                     int window_size, float *u, float *v)
+{
+    int rc = check_hw(prev, curr, H, W);
+    if (rc) return rc;
+    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    std::lock_guard<std::mutex> lk(g_mu);
+    oflk_plan *p = nullptr;
+    rc = host_plan(B, H, W, 1, window_size, 0, &p);
+    if (rc) return rc;
+    size_t bytes = (size_t)B * H * W * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(g_io[0], prev, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(g_io[1], curr, bytes, hipMemcpyHostToDevice, nullptr));
+    rc = oflk_plan_single_scale(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_single_scale(const float *prev, const float *curr, int H, int W, int window_size,
+                               float *u, float *v)
+{
+    return oflk_single_scale_batch(prev, curr, 1, H, W, window_size, u, v);
+}
+
+OFLK_API int oflk_pyramidal_batch(const float *prev, const float *curr, int B, int H, int W,
+                                  int levels, int window_size, int iters, float *u, float *v,
+                                  float *residual_log, int *iters_run)
+{
+    int rc = check_hw(prev, curr, H, W);
+    if (rc) return rc;
+    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    std::lock_guard<std::mutex> lk(g_mu);
+    oflk_plan *p = nullptr;
+    rc = host_plan(B, H, W, levels, window_size, iters, &p);
+    if (rc) return rc;
+    size_t bytes = (size_t)B * H * W * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(g_io[0], prev, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(g_io[1], curr, bytes, hipMemcpyHostToDevice, nullptr));
+    rc = oflk_plan_pyramidal(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    return oflk_plan_read_log(p, residual_log, iters_run, nullptr);
+}
+
+OFLK_API int oflk_pyramidal(const float *prev, const float *curr, int H, int W, int levels,
+                            int window_size, int iters, float *u, float *v, float *residual_log,
+                            int *iters_run)
+{
+    return oflk_pyramidal_batch(prev, curr, 1, H, W, levels, window_size, iters, u, v, residual_log,
+                                iters_run);
+}
+
+OFLK_API int oflk_compute_gradients(const float *prev, const float *curr, int H, int W, float *Ix,
+                                    float *Iy, float *It)
+{
+    int rc = check_hw(prev, curr, H, W);
+    if (rc) return rc;
+    if (!Ix || !Iy || !It) return fail(OFLK_ERR_INVALID, "NULL output");
+    std::lock_guard<std::mutex> lk(g_mu);
+    rc = ensure_device(g_device);
+    if (rc) return rc;
+    Arena ar;
+    size_t n = (size_t)H * W, bytes = n * sizeof(float);
+    float *d[5];
+    for (auto &q : d)
+        if ((rc = ar.get(&q, n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d[0], prev, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d[1], curr, bytes, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_gradients, grid2d(W, H, 1), dim3(256), 0, nullptr, (const float *)d[0],
+                       (const float *)d[1], d[2], d[3], d[4], H, W);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(Ix, d[2], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(Iy, d[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(It, d[4], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_from_gradients(const float *Ix, const float *Iy, const float *It, int H, int W,
+                                 int window_size, float *u, float *v)
+{
+    int rc = check_hw(Ix, Iy, H, W);
+    if (rc) return rc;
+    if (!It || !u || !v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    int hw = 0;
+    if ((rc = window_hw(window_size, &hw))) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    rc = ensure_device(g_device);
+    if (rc) return rc;
+    Arena ar;
+    size_t n = (size_t)H * W, bytes = n * sizeof(float);
+    float *d[5];
+    for (auto &q : d)
+        if ((rc = ar.get(&q, n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d[0], Ix, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d[1], Iy, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d[2], It, bytes, hipMemcpyHostToDevice, nullptr));
+    LkArgs a{};
+    a.prev = d[0]; a.curr = d[1]; a.aux = d[2];
+    a.fu[0] = d[3]; a.fv[0] = d[4];
+    a.H = H; a.W = W;
+    rc = launch_lk<MODE_GRADS>(nullptr, nullptr, KC_LK_SINGLE, hw, a, 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(u, d[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, d[4], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_build_pyramid(const float *image, int H, int W, int levels, double scale_factor,
+                                float *const *out_levels)
+{
+    int rc = check_hw(image, out_levels, H, W);
+    if (rc) return rc;
+    int dims[2 * OFLK_MAX_LEVELS];
+    if ((rc = level_dims(H, W, levels, scale_factor, dims))) return rc;
+    for (int l = 0; l < levels; l++)
+        if (!out_levels[l]) return fail(OFLK_ERR_INVALID, "out_levels[%d] is NULL", l);
+    std::lock_guard<std::mutex> lk(g_mu);
+    rc = ensure_device(g_device);
+    if (rc) return rc;
+    GaussW gauss;
+    if ((rc = make_gauss(1.0 / scale_factor, &gauss))) return rc;
+    Arena ar;
+    size_t N = (size_t)H * W;
+    float *cur = nullptr, *nxt = nullptr, *tA = nullptr, *tB = nullptr;
+    if ((rc = ar.get(&cur, N)) || (rc = ar.get(&nxt, N)) || (rc = ar.get(&tA, N)) || (rc = ar.get(&tB, N)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(cur, image, N * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    std::memcpy(out_levels[levels - 1], image, N * sizeof(float));  // image.copy(), :40
+    for (int l = levels - 2; l >= 0; l--) {
+        int h = dims[2 * (l + 1)], w = dims[2 * (l + 1) + 1];
+        int ho = dims[2 * l], wo = dims[2 * l + 1];
+        rc = launch_pyr_down(nullptr, gauss, nullptr, cur, nxt, tA, tB, 1, h, w, ho, wo);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_levels[l], nxt, (size_t)ho * wo * sizeof(float), hipMemcpyDeviceToHost,
+                               nullptr));
+        std::swap(cur, nxt);
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_warp(const float *image, const float *flow_u, const float *flow_v, int H, int W,
+                       float *out)
+{
+    int rc = check_hw(image, flow_u, H, W);
+    if (rc) return rc;
+    if (!flow_v || !out) return fail(OFLK_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    rc = ensure_device(g_device);
+    if (rc) return rc;
+    Arena ar;
+    size_t n = (size_t)H * W, bytes = n * sizeof(float);
+    float *d[4];
+    for (auto &q : d)
+        if ((rc = ar.get(&q, n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d[0], image, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d[1], flow_u, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d[2], flow_v, bytes, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_warp, grid2d(W, H, 1), dim3(256), 0, nullptr, (const float *)d[0],
+                       (const float *)d[1], (const float *)d[2], d[3], H, W);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_upsample_flow(const float *flow_u, const float *flow_v, int Hc, int Wc, int Ht,
+                                int Wt, float *u_out, float *v_out)
+{
+    int rc = check_hw(flow_u, flow_v, Hc, Wc);
+    if (rc) return rc;
+    if ((rc = check_hw(u_out, v_out, Ht, Wt))) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    rc = ensure_device(g_device);
+    if (rc) return rc;
+    Arena ar;
+    size_t nc = (size_t)Hc * Wc, nt = (size_t)Ht * Wt;
+    float *du = nullptr, *dv = nullptr, *ou = nullptr, *ov = nullptr;
+    if ((rc = ar.get(&du, nc)) || (rc = ar.get(&dv, nc)) || (rc = ar.get(&ou, nt)) || (rc = ar.get(&ov, nt)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(du, flow_u, nc * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(dv, flow_v, nc * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    ResampleArgs r{};
+    r.in[0] = du; r.in[1] = dv;
+    r.out[0] = ou; r.out[1] = ov;
+    r.scale[0] = (float)((double)Wt / (double)Wc);
+    r.scale[1] = (float)((double)Ht / (double)Hc);
+    r.H = Hc; r.W = Wc; r.Ho = Ht; r.Wo = Wt;
+    r.ly = make_linspace(Hc, Ht);
+    r.lx = make_linspace(Wc, Wt);
+    r.nplanes = 2;
+    r.apply_scale = 1;
+    hipLaunchKernelGGL(k_resample, grid2d(Wt, Ht, 1), dim3(256), 0, nullptr, r);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(u_out, ou, nt * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v_out, ov, nt * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}

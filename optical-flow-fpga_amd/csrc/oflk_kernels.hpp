@@ -1,0 +1,594 @@
+// oflk_kernels.hpp -- gfx950 device code for dense Lucas-Kanade optical flow.
+//
+// Numerics contract (DESIGN.md "Exactness"): every kernel reproduces the IEEE
+// operation sequence of the reference's NumPy/SciPy calls, so results are equal
+// to the reference's value for value:
+//   - fp32 stages (Sobel, products, window sums, 2x2 solve, flow accumulate) use
+//     individually rounded fp32 ops in NumPy's order; the translation unit is
+//     compiled with -ffp-contract=off and correctly rounded fp32 division;
+//   - SciPy stages (Gaussian, bilinear sampling) accumulate in fp64 and round to
+//     fp32 exactly where SciPy stores fp32.
+// Reference line numbers are relative to /root/reference/python/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace oflk {
+
+constexpr int kMaxRadius = 64;
+
+// ---------------------------------------------------------------------------
+// scipy.ndimage.map_coordinates(order=1, mode="constant", cval=0) at one point
+// (lucas_kanade_pyramidal.py:59, :95, :131-132).  fp64 coordinates, weights
+// w0 = 1 - frac, w1 = 1 - w0, taps accumulated (y0,x0),(y0,x1),(y1,x0),(y1,x1),
+// each as (p * wy) * wx; hard zero outside [0, N-1].
+// ---------------------------------------------------------------------------
+struct BilinearTaps {
+    int i00, i01, i10, i11;  // element offsets into the plane
+    double wy0, wy1, wx0, wx1;
+    bool inside;
+};
+
+__device__ __forceinline__ BilinearTaps bilinear_taps(int H, int W, double y, double x)
+{
+    BilinearTaps t;
+    t.inside = !(y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1));
+    double fy = floor(y), fx = floor(x);
+    int y0 = (int)fy, x0 = (int)fx;
+    // keep addresses legal for non-finite coordinates (never produced from finite
+    // inputs; the value is discarded or multiplied into NaN anyway)
+    y0 = min(max(y0, 0), H - 1);
+    x0 = min(max(x0, 0), W - 1);
+    double ry = y - fy, rx = x - fx;
+    t.wy0 = 1.0 - ry;
+    t.wx0 = 1.0 - rx;
+    t.wy1 = 1.0 - t.wy0;
+    t.wx1 = 1.0 - t.wx0;
+    // a tap past the last index only occurs with weight exactly 0; SciPy reads
+    // the mirrored element there
+    int y1 = (y0 + 1 < H) ? y0 + 1 : (H > 1 ? H - 2 : 0);
+    int x1 = (x0 + 1 < W) ? x0 + 1 : (W > 1 ? W - 2 : 0);
+    t.i00 = y0 * W + x0;
+    t.i01 = y0 * W + x1;
+    t.i10 = y1 * W + x0;
+    t.i11 = y1 * W + x1;
+    return t;
+}
+
+__device__ __forceinline__ float bilinear_apply(const float *__restrict__ img, const BilinearTaps &t)
+{
+    if (!t.inside) return 0.0f;
+    double acc = 0.0, c;
+    c = (double)img[t.i00]; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
+    c = (double)img[t.i01]; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
+    c = (double)img[t.i10]; c = c * t.wy1; c = c * t.wx0; acc = acc + c;
+    c = (double)img[t.i11]; c = c * t.wy1; c = c * t.wx1; acc = acc + c;
+    return (float)acc;
+}
+
+__device__ __forceinline__ float bilinear_f64(const float *__restrict__ img, int H, int W, double y,
+                                              double x)
+{
+    BilinearTaps t = bilinear_taps(H, W, y, x);
+    return bilinear_apply(img, t);
+}
+
+// np.linspace(0, S-1, T)[i]; `step` = (double)(S-1)/(double)(T-1) from the host
+struct Linspace {
+    double step;
+    double last;  // S - 1
+    int T;
+};
+
+__device__ __forceinline__ double linspace_at(const Linspace &l, int i)
+{
+    if (l.T <= 1) return 0.0;
+    if (i == l.T - 1) return l.last;
+    return (double)i * l.step;  // step == 0 (S == 1) also yields 0, as NumPy does
+}
+
+// ---------------------------------------------------------------------------
+// NumPy pairwise sum of a (2HW+1)^2 window, n <= 128: 8 strided accumulators,
+// fixed tree, sequential tail (lucas_kanade_core.py:115-119 via np.sum).  The
+// window of output O (0..3 along x) lives in v[row][O + col].
+// ---------------------------------------------------------------------------
+template <int HW, int O>
+__device__ __forceinline__ float np_window_sum(const float (&v)[2 * HW + 1][4 + 2 * HW])
+{
+    constexpr int S = 2 * HW + 1;
+    constexpr int N = S * S;
+    static_assert(N >= 8 && N <= 128, "window must fit NumPy's unrolled pairwise block");
+    constexpr int NB = N - (N % 8);
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = v[j / S][O + j % S];
+#pragma unroll
+    for (int i = 8; i < NB; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = r[j] + v[(i + j) / S][O + (i + j) % S];
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int i = NB; i < N; i++) res = res + v[i / S][O + i % S];
+    // the add-reduction starts from the identity: 0 + res (only turns -0 into +0)
+    return 0.0f + res;
+}
+
+// 2x2 Cramer solve, every op individually rounded (lucas_kanade_core.py:122-133)
+__device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float Sxt, float Syt,
+                                         float &u, float &v)
+{
+    float b0 = -Sxt, b1 = -Syt;
+    float m0 = Sxx * Syy;
+    float m1 = Sxy * Sxy;
+    float det = m0 - m1;
+    u = 0.0f;
+    v = 0.0f;
+    if (fabsf(det) > 1e-4f) {  // float32(1e-4), see oracle/oflk_oracle.c
+        float n0 = Syy * b0, n1 = Sxy * b1;
+        float n2 = Sxx * b1, n3 = Sxy * b0;
+        float nu = n0 - n1, nv = n2 - n3;
+        u = nu / det;
+        v = nv / det;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1/K7: fused Lucas-Kanade tile kernel.
+//   MODE_SINGLE : lucas_kanade_single_scale(prev, curr)            -> u, v
+//   MODE_ITER   : one pyramid iteration (lucas_kanade_pyramidal.py:203-214):
+//                 warp(curr, flow) -> LK(prev, warped) -> flow_out = flow_in + d,
+//                 per-block sums of |du|, |dv|
+//   MODE_GRADS  : lucas_kanade_from_gradients(Ix, Iy, It)           -> u, v
+// One 256-thread block produces a 64 x 16 output tile; each thread 1 x 4 outputs.
+// LDS: frame-average tile with halo HW+1, It tile and five product planes with
+// halo HW.  HBM traffic per output pixel: 8 B in + 8 B out (SINGLE), 16 B in +
+// 8 B out (ITER; the warp's gathers of `curr` hit L1/L2).
+// ---------------------------------------------------------------------------
+enum { MODE_SINGLE = 0, MODE_ITER = 1, MODE_GRADS = 2 };
+
+constexpr int kTX = 64;
+constexpr int kTY = 16;
+constexpr int kLkThreads = 256;
+
+struct LkArgs {
+    const float *prev;  // [B][H][W]   (MODE_GRADS: Ix)
+    const float *curr;  // [B][H][W]   (MODE_GRADS: Iy)
+    const float *aux;   // MODE_GRADS: It
+    float *fu[2];       // flow ping-pong buffers, [B][H][W]; SINGLE/GRADS write fu[0]
+    float *fv[2];
+    double *partial;    // ITER: [B][nblk][2] block sums of |du|, |dv|
+    const int *sel;     // ITER: per pair, which of fu[]/fv[] holds the current flow
+    const int *done;    // ITER: per pair, level already converged -> skip
+    int H, W;
+};
+
+template <int HW, int MODE>
+__global__ __launch_bounds__(kLkThreads) void k_lk(LkArgs a)
+{
+    constexpr int R = HW + 1;             // halo of the frame-average tile
+    constexpr int AH = kTY + 2 * R;
+    constexpr int AW = kTX + 2 * R;
+    constexpr int AS = AW + 1;            // +1: odd stride for the column-ish Sobel reads
+    constexpr int PH = kTY + 2 * HW;      // gradient / product tile
+    constexpr int PW = kTX + 2 * HW;
+    constexpr int PS = (PW + 3) & ~3;     // rows stay 16-byte aligned for ds_read_b128
+    constexpr int S = 2 * HW + 1;
+    constexpr int NV = 4 + 2 * HW;        // product columns one thread needs per row
+
+    __shared__ float s_avg[MODE == MODE_GRADS ? 1 : AH * AS];
+    __shared__ float s_it[MODE == MODE_GRADS ? 1 : PH * PS];
+    __shared__ __attribute__((aligned(16))) float s_p[5][PH * PS];
+
+    const int b = blockIdx.z;
+    int sel = 0;
+    if (MODE == MODE_ITER) {
+        if (a.done[b]) return;  // block-uniform: level converged for this pair
+        sel = a.sel[b];
+    }
+    const int H = a.H, W = a.W;
+    const size_t plane = (size_t)H * (size_t)W;
+    const float *__restrict__ prev = a.prev + (size_t)b * plane;
+    const float *__restrict__ curr = a.curr + (size_t)b * plane;
+    const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
+    const int tid = threadIdx.x;
+
+    if (MODE == MODE_GRADS) {
+        // products straight from the caller's gradients
+        const float *__restrict__ gxp = prev;
+        const float *__restrict__ gyp = curr;
+        const float *__restrict__ gtp = a.aux + (size_t)b * plane;
+        for (int e = tid; e < PH * PW; e += kLkThreads) {
+            int r = e / PW, c = e - r * PW;
+            int gy = y0 - HW + r, gx = x0 - HW + c;
+            float ix = 0.0f, iy = 0.0f, it = 0.0f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                size_t i = (size_t)gy * W + gx;
+                ix = gxp[i];
+                iy = gyp[i];
+                it = gtp[i];
+            }
+            int o = r * PS + c;
+            s_p[0][o] = ix * ix;
+            s_p[1][o] = iy * iy;
+            s_p[2][o] = ix * iy;
+            s_p[3][o] = ix * it;
+            s_p[4][o] = iy * it;
+        }
+    } else {
+        // ---- stage 1: second frame (warped if ITER), frame average, It -------
+        const float *__restrict__ fu_in = nullptr;
+        const float *__restrict__ fv_in = nullptr;
+        if (MODE == MODE_ITER) {
+            fu_in = a.fu[sel] + (size_t)b * plane;
+            fv_in = a.fv[sel] + (size_t)b * plane;
+        }
+        for (int e = tid; e < AH * AW; e += kLkThreads) {
+            int r = e / AW, c = e - r * AW;
+            // convolve2d boundary="symm": one ring of edge repetition; farther-out
+            // halo cells only feed windows that are never evaluated
+            int gy = min(max(y0 - R + r, 0), H - 1);
+            int gx = min(max(x0 - R + c, 0), W - 1);
+            size_t i = (size_t)gy * W + gx;
+            float p = prev[i];
+            float q;
+            if (MODE == MODE_ITER) {
+                // warp_image (lucas_kanade_pyramidal.py:88-95)
+                double xs = (double)gx + (double)fu_in[i];
+                double ys = (double)gy + (double)fv_in[i];
+                q = bilinear_f64(curr, H, W, ys, xs);
+            } else {
+                q = curr[i];
+            }
+            float sum = p + q;
+            s_avg[r * AS + c] = sum * 0.5f;  // (prev + curr) / 2.0, lucas_kanade_core.py:36
+            if (r >= 1 && r < AH - 1 && c >= 1 && c < AW - 1)
+                s_it[(r - 1) * PS + (c - 1)] = p - q;  // lucas_kanade_core.py:43
+        }
+        __syncthreads();
+        // ---- stage 2: Sobel/8 as convolve2d evaluates it, then the 5 products -
+        for (int e = tid; e < PH * PW; e += kLkThreads) {
+            int r = e / PW, c = e - r * PW;
+            const float *ap = &s_avg[(r + 1) * AS + (c + 1)];
+            float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
+            float a_0m = ap[-1], a_0p = ap[1];
+            float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
+            // kernel taps in row-major order of the flipped kernel; products by
+            // powers of two are exact, so fma(a, w, s) == fl(s + fl(a*w))
+            float ix = a_pp * -0.125f;
+            ix = fmaf(a_pm, 0.125f, ix);
+            ix = fmaf(a_0p, -0.25f, ix);
+            ix = fmaf(a_0m, 0.25f, ix);
+            ix = fmaf(a_mp, -0.125f, ix);
+            ix = fmaf(a_mm, 0.125f, ix);
+            float iy = a_pp * -0.125f;
+            iy = fmaf(a_p0, -0.25f, iy);
+            iy = fmaf(a_pm, -0.125f, iy);
+            iy = fmaf(a_mp, 0.125f, iy);
+            iy = fmaf(a_m0, 0.25f, iy);
+            iy = fmaf(a_mm, 0.125f, iy);
+            int o = r * PS + c;
+            float it = s_it[o];
+            s_p[0][o] = ix * ix;
+            s_p[1][o] = iy * iy;
+            s_p[2][o] = ix * iy;
+            s_p[3][o] = ix * it;
+            s_p[4][o] = iy * it;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 3: window sums in NumPy order, solve, write -------------------
+    const int tx = tid & 15, ty = tid >> 4;
+    float sums[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float v[S][NV];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const float *row = &s_p[k][(ty + i) * PS + 4 * tx];
+#pragma unroll
+            for (int j = 0; j + 4 <= NV; j += 4) {
+                float4 q = *reinterpret_cast<const float4 *>(row + j);
+                v[i][j] = q.x; v[i][j + 1] = q.y; v[i][j + 2] = q.z; v[i][j + 3] = q.w;
+            }
+            if (NV % 4 == 2) {
+                float2 q = *reinterpret_cast<const float2 *>(row + (NV - 2));
+                v[i][NV - 2] = q.x; v[i][NV - 1] = q.y;
+            }
+        }
+        sums[k][0] = np_window_sum<HW, 0>(v);
+        sums[k][1] = np_window_sum<HW, 1>(v);
+        sums[k][2] = np_window_sum<HW, 2>(v);
+        sums[k][3] = np_window_sum<HW, 3>(v);
+    }
+
+    const int gy = y0 + ty;
+    const int gxb = x0 + 4 * tx;
+    float du[4], dv[4];
+    double su = 0.0, sv = 0.0;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        float u, v;
+        lk_solve(sums[0][o], sums[1][o], sums[2][o], sums[3][o], sums[4][o], u, v);
+        int gx = gxb + o;
+        // borders stay zero (lucas_kanade_core.py:101-108)
+        bool interior = gy >= HW && gy < H - HW && gx >= HW && gx < W - HW;
+        du[o] = interior ? u : 0.0f;
+        dv[o] = interior ? v : 0.0f;
+        if (MODE == MODE_ITER && gy < H && gx < W) {
+            su += (double)fabsf(du[o]);
+            sv += (double)fabsf(dv[o]);
+        }
+    }
+
+    float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
+    float *__restrict__ ov = a.fv[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
+    if (gy < H && gxb < W) {
+        size_t i = (size_t)gy * W + gxb;
+        if (((W & 3) == 0) && gxb + 3 < W) {
+            float4 ru = make_float4(du[0], du[1], du[2], du[3]);
+            float4 rv = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            if (MODE == MODE_ITER) {
+                // flow += d (lucas_kanade_pyramidal.py:209-210)
+                float4 pu = *reinterpret_cast<const float4 *>(a.fu[sel] + (size_t)b * plane + i);
+                float4 pv = *reinterpret_cast<const float4 *>(a.fv[sel] + (size_t)b * plane + i);
+                ru.x = pu.x + ru.x; ru.y = pu.y + ru.y; ru.z = pu.z + ru.z; ru.w = pu.w + ru.w;
+                rv.x = pv.x + rv.x; rv.y = pv.y + rv.y; rv.z = pv.z + rv.z; rv.w = pv.w + rv.w;
+            }
+            *reinterpret_cast<float4 *>(ou + i) = ru;
+            *reinterpret_cast<float4 *>(ov + i) = rv;
+        } else {
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if (gxb + o < W) {
+                    float ru = du[o], rv = dv[o];
+                    if (MODE == MODE_ITER) {
+                        ru = a.fu[sel][(size_t)b * plane + i + o] + ru;
+                        rv = a.fv[sel][(size_t)b * plane + i + o] + rv;
+                    }
+                    ou[i + o] = ru;
+                    ov[i + o] = rv;
+                }
+            }
+        }
+    }
+
+    if (MODE == MODE_ITER) {
+        // fixed-order block reduction of the |d| sums (fp64)
+        __shared__ double s_red[2][kLkThreads / 64];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            su += __shfl_down(su, off, 64);
+            sv += __shfl_down(sv, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            s_red[0][tid >> 6] = su;
+            s_red[1][tid >> 6] = sv;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double tu = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+            double tv = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+            size_t nblk = (size_t)gridDim.x * gridDim.y;
+            size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            a.partial[((size_t)b * nblk + blk) * 2 + 0] = tu;
+            a.partial[((size_t)b * nblk + blk) * 2 + 1] = tv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6: per-pair residual means, log, convergence flag
+// (lucas_kanade_pyramidal.py:213-223).  One block per pair; fixed summation
+// order, fp64.  The reference's np.mean is an fp32 pairwise sum; the two agree
+// to ~1e-7 relative, which can flip the "< 0.01" test only when the mean sits
+// within that distance of the threshold (DESIGN.md "Known deviations").
+// ---------------------------------------------------------------------------
+struct FinalizeArgs {
+    const double *partial;  // [B][nblk][2]
+    int nblk;
+    double count;           // H*W of the level
+    float *log;             // [B][L][K][2]
+    int *iters_run;         // [B][L]
+    int *sel;               // [B] (this level)
+    int *done;              // [B] (this level)
+    int level, iter, L, K;
+};
+
+__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a)
+{
+    const int b = blockIdx.x;
+    if (a.done[b]) return;
+    const int tid = threadIdx.x;
+    double su = 0.0, sv = 0.0;
+    const double *p = a.partial + (size_t)b * a.nblk * 2;
+    for (int i = tid; i < a.nblk; i += 256) {
+        su += p[2 * i];
+        sv += p[2 * i + 1];
+    }
+    __shared__ double s_u[256], s_v[256];
+    s_u[tid] = su;
+    s_v[tid] = sv;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            s_u[tid] += s_u[tid + off];
+            s_v[tid] += s_v[tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float mu = (float)(s_u[0] / a.count);
+        float mv = (float)(s_v[0] / a.count);
+        size_t li = (((size_t)b * a.L + a.level) * a.K + a.iter) * 2;
+        a.log[li] = mu;
+        a.log[li + 1] = mv;
+        a.iters_run[b * a.L + a.level] = a.iter + 1;
+        a.sel[b] ^= 1;
+        if (mu < 0.01f && mv < 0.01f) a.done[b] = 1;  // :221-223
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: Gaussian blur (scipy.ndimage.gaussian_filter -> correlate1d, symmetric
+// branch): fp64 accumulation  tmp = x[c]*w0; for k = r..1: tmp += (x[c-k]+x[c+k])*w[k],
+// fp32 store after each axis (lucas_kanade_pyramidal.py:46-47).
+// ---------------------------------------------------------------------------
+struct GaussW {
+    double w[kMaxRadius + 1];
+    int radius;
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    // scipy.ndimage "reflect": (d c b a | a b c d | d c b a)
+    if (i >= 0 && i < n) return i;
+    if (n == 1) return 0;
+    int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+// AXIS 0: along y (columns), AXIS 1: along x (rows)
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_blur(const float *__restrict__ in, float *__restrict__ out,
+                                              int H, int W, GaussW g)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t plane = (size_t)H * (size_t)W;
+    const float *__restrict__ src = in + (size_t)blockIdx.z * plane;
+    const int len = AXIS == 0 ? H : W;
+    const int c = AXIS == 0 ? y : x;
+    auto at = [&](int i) -> double {
+        int j = reflect_idx(i, len);
+        return (double)(AXIS == 0 ? src[(size_t)j * W + x] : src[(size_t)y * W + j]);
+    };
+    double tmp = at(c) * g.w[0];
+    for (int k = g.radius; k >= 1; k--) {
+        double s = at(c - k) + at(c + k);
+        double m = s * g.w[k];
+        tmp = tmp + m;
+    }
+    out[(size_t)blockIdx.z * plane + (size_t)y * W + x] = (float)tmp;
+}
+
+// bilinear sampling on the linspace(0,H-1,Ho) x linspace(0,W-1,Wo) grid
+// (lucas_kanade_pyramidal.py:55-59); NPL planes resampled with shared taps, each
+// optionally scaled in fp32 afterwards (upsample_flow, :126-136).
+struct ResampleArgs {
+    const float *in[2];   // [nimg][H][W] each
+    float *out[2];        // [nimg][Ho][Wo]
+    const int *sel;       // optional: per image, add sel[img]*in_sel_stride to in[] (flow ping-pong)
+    size_t in_sel_stride; // elements between ping-pong buffers (0 when unused)
+    float scale[2];
+    int H, W, Ho, Wo;
+    Linspace ly, lx;
+    int nplanes;          // 1 or 2
+    int apply_scale;
+};
+
+__global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
+{
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= a.Wo || i >= a.Ho) return;
+    const int img = blockIdx.z;
+    const size_t ip = (size_t)a.H * a.W, op = (size_t)a.Ho * a.Wo;
+    size_t selofs = 0;
+    if (a.sel) selofs = (size_t)a.sel[img] * a.in_sel_stride;
+    double y = linspace_at(a.ly, i);
+    double x = linspace_at(a.lx, j);
+    BilinearTaps t = bilinear_taps(a.H, a.W, y, x);
+    for (int p = 0; p < a.nplanes; p++) {
+        float r = bilinear_apply(a.in[p] + selofs + (size_t)img * ip, t);
+        if (a.apply_scale) r = r * a.scale[p];
+        a.out[p][(size_t)img * op + (size_t)i * a.Wo + j] = r;
+    }
+}
+
+// K3 standalone: warp_image (lucas_kanade_pyramidal.py:66-97)
+__global__ __launch_bounds__(256) void k_warp(const float *__restrict__ img,
+                                              const float *__restrict__ fu,
+                                              const float *__restrict__ fv, float *__restrict__ out,
+                                              int H, int W)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t plane = (size_t)H * (size_t)W;
+    const size_t base = (size_t)blockIdx.z * plane;
+    size_t i = (size_t)y * W + x;
+    double xs = (double)x + (double)fu[base + i];
+    double ys = (double)y + (double)fv[base + i];
+    out[base + i] = bilinear_f64(img + base, H, W, ys, xs);
+}
+
+// a1 standalone: compute_gradients (lucas_kanade_core.py:15-45)
+__global__ __launch_bounds__(256) void k_gradients(const float *__restrict__ prev,
+                                                   const float *__restrict__ curr,
+                                                   float *__restrict__ Ix, float *__restrict__ Iy,
+                                                   float *__restrict__ It, int H, int W)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t base = (size_t)blockIdx.z * (size_t)H * (size_t)W;
+    auto avg = [&](int yy, int xx) -> float {
+        yy = min(max(yy, 0), H - 1);
+        xx = min(max(xx, 0), W - 1);
+        size_t i = base + (size_t)yy * W + xx;
+        float s = prev[i] + curr[i];
+        return s * 0.5f;
+    };
+    float a_mm = avg(y - 1, x - 1), a_m0 = avg(y - 1, x), a_mp = avg(y - 1, x + 1);
+    float a_0m = avg(y, x - 1), a_0p = avg(y, x + 1);
+    float a_pm = avg(y + 1, x - 1), a_p0 = avg(y + 1, x), a_pp = avg(y + 1, x + 1);
+    float ix = a_pp * -0.125f;
+    ix = fmaf(a_pm, 0.125f, ix);
+    ix = fmaf(a_0p, -0.25f, ix);
+    ix = fmaf(a_0m, 0.25f, ix);
+    ix = fmaf(a_mp, -0.125f, ix);
+    ix = fmaf(a_mm, 0.125f, ix);
+    float iy = a_pp * -0.125f;
+    iy = fmaf(a_p0, -0.25f, iy);
+    iy = fmaf(a_pm, -0.125f, iy);
+    iy = fmaf(a_mp, 0.125f, iy);
+    iy = fmaf(a_m0, 0.25f, iy);
+    iy = fmaf(a_mm, 0.125f, iy);
+    size_t i = base + (size_t)y * W + x;
+    Ix[i] = ix;
+    Iy[i] = iy;
+    It[i] = prev[i] - curr[i];
+}
+
+// copy the finest-level flow of pairs whose result did not land in the caller's
+// buffers (early exit changed the ping-pong parity); no-op blocks otherwise
+struct ExportArgs {
+    const float *src_u, *src_v;  // internal buffers [B][H][W]
+    float *dst_u, *dst_v;        // caller's buffers
+    const int *sel;              // [B]
+    int want;                    // buffer index that is the caller's
+    size_t plane;
+};
+
+__global__ __launch_bounds__(256) void k_export_fixup(ExportArgs a)
+{
+    const int b = blockIdx.y;
+    if (a.sel[b] == a.want) return;
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t base = (size_t)b * a.plane;
+    for (int k = 0; k < 4; k++) {
+        if (i + k < a.plane) {
+            a.dst_u[base + i + k] = a.src_u[base + i + k];
+            a.dst_v[base + i + k] = a.src_v[base + i + k];
+        }
+    }
+}
+
+}  // namespace oflk

@@ -1,0 +1,169 @@
+"""ctypes binding of liboflk.so (include/oflk.h) -- the only native dependency of
+the drop-in modules in this directory.
+
+There is no CPU fallback: if the library is missing, or no MI355X-class GPU is
+usable, every call raises.  Build with ``python __graft_entry__.py`` (or
+``make -C optical-flow-fpga_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("OFLK_LIB", _HERE.parent / "liboflk.so"))
+
+OFLK_OK = 0
+OFLK_ERR_INVALID = -1
+OFLK_ERR_NO_DEVICE = -2
+OFLK_ERR_HIP = -3
+OFLK_ERR_UNSUPPORTED = -4
+OFLK_ERR_NOMEM = -5
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+# every exported symbol of include/oflk.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "oflk_version": (ctypes.c_char_p, []),
+    "oflk_device_count": (ctypes.c_int, []),
+    "oflk_last_error": (ctypes.c_char_p, []),
+    "oflk_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "oflk_compute_gradients": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p]),
+    "oflk_from_gradients": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
+    "oflk_single_scale": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
+    "oflk_pyramid_level_dims": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _i32p]),
+    "oflk_build_pyramid": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(_f32p)]),
+    "oflk_warp": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, _f32p]),
+    "oflk_upsample_flow": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
+    "oflk_pyramidal": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
+    "oflk_single_scale_batch": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
+    "oflk_pyramidal_batch": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
+    "oflk_plan_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "oflk_plan_destroy": (ctypes.c_int, [_vp]),
+    "oflk_plan_workspace_bytes": (ctypes.c_size_t, [_vp]),
+    "oflk_plan_single_scale": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "oflk_plan_pyramidal": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "oflk_plan_read_log": (ctypes.c_int, [_vp, _f32p, _i32p, _vp]),
+    "oflk_plan_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "oflk_plan_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class OflkError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"liboflk error {code}: {message}")
+        self.code = code
+
+
+def lib() -> ctypes.CDLL:
+    """Load liboflk.so once; raise loudly when it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `python __graft_entry__.py` or `make -C optical-flow-fpga_amd/csrc`. "
+                "There is no CPU fallback."
+            )
+        L = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != OFLK_OK:
+        msg = lib().oflk_last_error().decode("utf-8", "replace")
+        if rc == OFLK_ERR_INVALID:
+            raise ValueError(f"liboflk: {msg}")
+        raise OflkError(rc, msg)
+
+
+def version() -> str:
+    return lib().oflk_version().decode()
+
+
+def device_count() -> int:
+    return int(lib().oflk_device_count())
+
+
+def as_f32(a) -> np.ndarray:
+    """What the reference's callers hand over: float32 [H, W]; convert anything else."""
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    if arr.ndim != 2:
+        raise ValueError(f"expected a 2-D array, got shape {arr.shape}")
+    return arr
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def same_shape(*arrs: np.ndarray) -> Tuple[int, int]:
+    s = arrs[0].shape
+    for a in arrs[1:]:
+        if a.shape != s:
+            raise ValueError(f"shape mismatch: {s} vs {a.shape}")
+    return int(s[0]), int(s[1])
+
+
+class Plan:
+    """Device-resident plan (oflk_plan_*): B pairs of H x W, pointers are raw
+    device addresses (e.g. torch.Tensor.data_ptr()), stream a hipStream_t handle."""
+
+    def __init__(self, device: int, B: int, H: int, W: int, levels: int = 3, window_size: int = 5,
+                 iters: int = 3):
+        self._h = _vp()
+        self.B, self.H, self.W, self.levels, self.window_size, self.iters = B, H, W, levels, window_size, iters
+        check(lib().oflk_plan_create(ctypes.byref(self._h), device, B, H, W, levels, window_size, iters))
+
+    def close(self) -> None:
+        if self._h:
+            lib().oflk_plan_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(lib().oflk_plan_workspace_bytes(self._h))
+
+    def single_scale(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0) -> None:
+        check(lib().oflk_plan_single_scale(self._h, d_prev, d_curr, d_u, d_v, stream))
+
+    def pyramidal(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0) -> None:
+        check(lib().oflk_plan_pyramidal(self._h, d_prev, d_curr, d_u, d_v, stream))
+
+    def read_log(self, stream: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        log = np.zeros((self.B, self.levels, max(self.iters, 1), 2), np.float32)
+        runs = np.zeros((self.B, self.levels), np.int32)
+        check(lib().oflk_plan_read_log(self._h, ptr(log), runs.ctypes.data_as(_i32p), stream))
+        return log, runs
+
+    def set_profiling(self, enabled: bool) -> None:
+        check(lib().oflk_plan_set_profiling(self._h, 1 if enabled else 0))
+
+    def kernel_times(self) -> dict:
+        n = 32
+        names = (ctypes.c_char_p * n)()
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_long * n)()
+        k = lib().oflk_plan_kernel_times(self._h, names, ms, cnt, n)
+        if k < 0:
+            check(k)
+        return {names[i].decode(): {"total_ms": ms[i], "launches": cnt[i]} for i in range(k)}

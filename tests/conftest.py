@@ -1,0 +1,38 @@
+"""pytest configuration: the `gpu` marker and import paths.
+
+- product modules (drop-in names) live in optical-flow-fpga_amd/python
+- the CPU oracle (test infrastructure) lives in oracle/
+"""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+PRODUCT = ROOT / "optical-flow-fpga_amd" / "python"
+ORACLE = ROOT / "oracle"
+GOLDEN = ROOT / "tests" / "golden"
+
+for p in (str(PRODUCT), str(ORACLE), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+os.environ.setdefault("OFLK_QUIET", "1")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oflk_oracle
+
+    oflk_oracle.build()
+    return oflk_oracle
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
