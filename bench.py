@@ -58,16 +58,16 @@ def main() -> None:
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--window", type=int, default=5)
     ap.add_argument("--iters", type=int, default=3)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=2)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=16, help="1080p pairs the CPU oracle is timed on (~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch  # first: liboflk then binds to the HIP runtime torch already loaded
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from oflk_dist import Group, env_rank
+
+    rank, local_rank, world = env_rank()
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
@@ -78,11 +78,7 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (no CPU path exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
-
-        dist.init_process_group("nccl", device_id=dev)
+    group = Group("nccl", dev)  # backend "nccl" is RCCL on ROCm; no-op for one rank
 
     import _oflk
     from oflk_synth import synth_pair
@@ -107,9 +103,8 @@ def main() -> None:
 
     def fence():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        group.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -122,10 +117,7 @@ def main() -> None:
     t1 = time.perf_counter()
     elapsed = t1 - t0
     fence()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.max_over_ranks(elapsed)
     ktimes = plan.kernel_times()
     plan.set_profiling(False)
     log, runs = plan.read_log(stream)
@@ -173,7 +165,7 @@ def main() -> None:
         cpu = {"value": round(n * H * W / (c1 - c0) / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
                "sample": f"{n} pairs {W}x{H}, {L}-level pyramidal {args.window}x{args.window} x{K} iters, "
                          f"oracle/oflk_oracle.c single thread, {c1 - c0:.1f} s"}
-        nt = O.max_threads()
+        nt = min(O.max_threads(), len(os.sched_getaffinity(0)), 16)  # the box's CPU share for one GPU
         if nt > 1:
             O.set_threads(nt)
             c0 = time.perf_counter()
@@ -208,8 +200,7 @@ def main() -> None:
         }
         print(json.dumps(out))
     plan.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

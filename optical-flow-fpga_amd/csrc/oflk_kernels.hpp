@@ -126,7 +126,7 @@ __device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float 
     float det = m0 - m1;
     u = 0.0f;
     v = 0.0f;
-    if (fabsf(det) > 1e-4f) {  // float32(1e-4), see oracle/oflk_oracle.c
+    if (fabsf(det) > 1e-4f) {  // compared as float32(1e-4), lucas_kanade_core.py:131
         float n0 = Syy * b0, n1 = Sxy * b1;
         float n2 = Sxx * b1, n3 = Sxy * b0;
         float nu = n0 - n1, nv = n2 - n3;

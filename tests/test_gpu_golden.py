@@ -1,0 +1,101 @@
+"""GPU tests against the reference's own outputs: the HIP path on the 13
+verification patterns must reproduce the sha256 digests of the flow fields the
+reference produced (tests/golden/reference_13patterns.json, made by importing the
+reference), i.e. EPE vs the Python reference is exactly 0 (bar in BASELINE.json:
+1e-4), and the verifier counterpart must reproduce verification_baseline.json."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PATTERNS = ["translate_small", "translate_medium", "translate_large", "translate_vertical", "translate_diagonal",
+            "rotate_small", "rotate_medium", "rotate_large", "zoom_in", "zoom_out", "translate_rotate", "no_motion",
+            "translate_extreme"]
+
+
+def digest(a):
+    a = np.ascontiguousarray(a, np.float32) + np.float32(0.0)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def suite(golden_dir):
+    return (np.load(golden_dir / "patterns_320x240.npz"),
+            json.loads((golden_dir / "reference_13patterns.json").read_text()))
+
+
+@pytest.mark.parametrize("name", PATTERNS)
+def test_hip_flow_equals_reference_flow(suite, name):
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+
+    z, ref = suite
+    p, c = z["frame_0"].astype(np.float32), z[f"frame_1__{name}"].astype(np.float32)
+    r = ref["patterns"][name]
+    u, v = K.lucas_kanade_single_scale(p, c, 5)
+    assert digest(u) == r["single_scale"]["u_sha256"] and digest(v) == r["single_scale"]["v_sha256"]
+    u, v, log, runs = P.lucas_kanade_pyramidal_with_log(p, c, 3, 5, 3)
+    assert list(runs) == r["pyramidal"]["iters_run"]
+    for l, rows in enumerate(r["pyramidal"]["residual_log"]):
+        # device means are an fp64 reduction; the reference's are an fp32 pairwise sum
+        np.testing.assert_allclose(log[l, :len(rows)], np.array(rows, np.float32), rtol=2e-6, atol=1e-9)
+    assert digest(u) == r["pyramidal"]["u_sha256"] and digest(v) == r["pyramidal"]["v_sha256"]
+
+
+def test_epe_vs_reference_dense(golden_dir, suite):
+    """the BASELINE.json parity metric, stated explicitly: mean EPE vs the reference flow <= 1e-4"""
+    import lucas_kanade_pyramidal as P
+
+    z, _ = suite
+    d = np.load(golden_dir / "dense_translate_medium.npz")
+    p, c = z["frame_0"].astype(np.float32), z["frame_1__translate_medium"].astype(np.float32)
+    u, v = P.lucas_kanade_pyramidal(p, c, 3, 5, 3)
+    epe = float(np.mean(np.sqrt((u.astype(np.float64) - d["pyr_u"]) ** 2 + (v.astype(np.float64) - d["pyr_v"]) ** 2)))
+    assert epe <= 1e-4  # tolerance of the north star
+    assert epe == 0.0   # what this build actually delivers
+
+
+def test_verifier_on_gpu_reproduces_baseline(tmp_path, golden_dir, suite, monkeypatch):
+    """the reference's CI recipe end to end on the HIP path: suite files -> verifier -> regression gate"""
+    import generate_test_suite as G
+    import optical_flow_verifier as V
+    from conftest import PRODUCT
+
+    z, ref = suite
+    suite_dir = tmp_path / "python" / "test_suite"
+    for name, params in G.TEST_PATTERNS.items():
+        pdir = suite_dir / name
+        pdir.mkdir(parents=True)
+        z["frame_0"].tofile(pdir / "frame_00.bin")
+        z[f"frame_1__{name}"].tofile(pdir / "frame_01.bin")
+        (pdir / "metadata.json").write_text(json.dumps({"resolution": {"width": 320, "height": 240},
+                                                        "motion_parameters": params.to_dict()}))
+    G.write_suite_index(suite_dir, 320, 240)
+    cfg = V.load_config(PRODUCT / "verification_config.yaml")
+    results = []
+    for name in V.load_test_suite_index(suite_dir)["patterns"]:
+        results.append(V.verify_pattern(name, V.load_test_pattern(suite_dir / name), cfg, verbose=False))
+    base = json.loads((golden_dir / "verification_baseline.json").read_text())["patterns"]
+    for r in results:
+        name = r["pattern_name"]
+        for key in ("single_scale", "pyramidal"):
+            assert r[key]["metrics"] == ref["patterns"][name][key]["metrics"], (name, key)
+            assert r[key]["status"] == base[name][key]["status"], (name, key)
+            for k, val in base[name][key]["metrics"].items():
+                assert abs(r[key]["metrics"][k] - val) <= 2e-5
+    assert V.compare_against_baseline(results, golden_dir / "verification_baseline.json", 10.0)
+
+
+def test_rtl_frame_pairs_on_gpu(golden_dir):
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+
+    r = np.load(golden_dir / "rtl_frames.npz")
+    for tag in ("natural", "sinusoid"):
+        p, c = r[f"{tag}__frame_00"].astype(np.float32), r[f"{tag}__frame_01"].astype(np.float32)
+        us, vs = K.lucas_kanade_single_scale(p, c, 5)
+        up, vp = P.lucas_kanade_pyramidal(p, c, 3, 5, 3)
+        assert [digest(us), digest(vs), digest(up), digest(vp)] == list(r[f"{tag}__sha"])

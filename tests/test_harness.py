@@ -1,0 +1,117 @@
+"""CPU tests of the host-side harness counterparts (pattern generator, metrics,
+verifier).  BASELINE config 1 -- `translate_small`, single-scale, driven through
+the verifier on CPU -- runs here with the ORACLE injected in place of the HIP
+functions: that is test plumbing (the shipped verifier imports the HIP drop-ins
+and has no CPU path)."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def V():
+    import optical_flow_verifier
+
+    return optical_flow_verifier
+
+
+@pytest.fixture(scope="module")
+def cfg(V):
+    from conftest import PRODUCT
+
+    return V.load_config(PRODUCT / "verification_config.yaml")
+
+
+def test_generator_reproduces_committed_patterns(golden_dir):
+    pytest.importorskip("PIL")
+    import generate_test_suite as G
+
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    base = G.load_base_texture(320, 240)
+    assert np.array_equal(base, z["frame_0"])
+    assert list(G.TEST_PATTERNS) == ["translate_small", "translate_medium", "translate_large", "translate_vertical",
+                                     "translate_diagonal", "rotate_small", "rotate_medium", "rotate_large", "zoom_in",
+                                     "zoom_out", "translate_rotate", "no_motion", "translate_extreme"]
+    for name, params in G.TEST_PATTERNS.items():
+        _, f1 = G.generate_test_pattern(params, base=base)
+        assert np.array_equal(f1, z[f"frame_1__{name}"]), name
+    # digests recorded in SURVEY.md Appendix B (reference-run verified there)
+    assert hashlib.sha256(base.tobytes()).hexdigest()[:12] == "29964567a77c"
+    assert hashlib.sha256(z["frame_1__translate_extreme"].tobytes()).hexdigest()[:12] == "152cb022c47e"
+
+
+def test_suite_files_round_trip(tmp_path, V, golden_dir):
+    pytest.importorskip("PIL")
+    import generate_test_suite as G
+
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    G.generate_full_suite(320, 240, tmp_path, base=z["frame_0"], save_png=False)
+    index = V.load_test_suite_index(tmp_path)
+    assert index["num_patterns"] == 13 and list(index["patterns"]) == list(G.TEST_PATTERNS)
+    d = V.load_test_pattern(tmp_path / "translate_small")
+    assert d["frame_prev"].dtype == np.float32 and d["frame_prev"].shape == (240, 320)
+    assert np.array_equal(d["frame_curr"], z["frame_1__translate_small"].astype(np.float32))
+    assert d["metadata"]["motion_parameters"]["dx"] == 0.5
+    mem = (tmp_path / "translate_small" / "frame_00.mem").read_text().split()
+    assert len(mem) == 320 * 240 and int(mem[0], 16) == int(z["frame_0"][0, 0])
+
+
+def test_masks_and_classification(V, cfg):
+    assert int(V.get_test_region_mask((240, 320), "translate_medium", 80).sum()) == 66000
+    assert int(V.get_test_region_mask((240, 320), "rotate_small", 80).sum()) == 6400
+    assert int(V.get_test_region_mask((240, 320), "translate_rotate", 80).sum()) == 6400
+    assert V.classify_result(0.4, 0.5, "translate_small", cfg) == "Pass"
+    assert V.classify_result(0.4, 0.51, "translate_small", cfg) == "Warning"
+    assert V.classify_result(2.1, 0.0, "translate_small", cfg) == "Fail"
+    assert V.classify_result(2.9, 0.0, "zoom_in", cfg) == "Warning"
+    assert V.get_thresholds_for_pattern("translate_rotate", cfg) == (2.0, 5.0)
+
+
+def test_compare_metrics_rules(V):
+    base = {"mae_u": 1.0, "mae_v": 0.0, "epe": 2.0}
+    ok = V.compare_metrics({"mae_u": 1.09, "mae_v": 0.0, "epe": 1.85}, base, 10.0)
+    assert ok["passed"] and set(ok["differences"]) == {"mae_u", "epe"}
+    bad = V.compare_metrics({"mae_u": 1.11, "mae_v": 1e-3, "epe": 2.0}, base, 10.0)
+    assert not bad["passed"] and len(bad["flags"]) == 2  # +11 % and "baseline was 0"
+
+
+def test_config1_translate_small_through_the_verifier(V, cfg, oracle, golden_dir, monkeypatch, capsys):
+    """BASELINE.json configs[0]: plumbing, no GPU -- oracle injected as the flow functions"""
+    monkeypatch.setattr(V, "lucas_kanade_single_scale", oracle.lucas_kanade_single_scale)
+    monkeypatch.setattr(V, "lucas_kanade_pyramidal",
+                        lambda p, c, num_levels, window_size, num_iterations:
+                        oracle.lucas_kanade_pyramidal(p, c, num_levels, window_size, num_iterations))
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    ref = json.loads((golden_dir / "reference_13patterns.json").read_text())["patterns"]["translate_small"]
+    data = {"frame_prev": z["frame_0"].astype(np.float32), "frame_curr": z["frame_1__translate_small"].astype(np.float32),
+            "metadata": {"motion_parameters": ref["motion"], "resolution": {"width": 320, "height": 240}}}
+    res = V.verify_pattern("translate_small", data, cfg, verbose=True)
+    assert res["num_test_pixels"] == 66000
+    assert res["single_scale"]["metrics"] == ref["single_scale"]["metrics"]
+    assert res["pyramidal"]["metrics"] == ref["pyramidal"]["metrics"]
+    base = json.loads((golden_dir / "verification_baseline.json").read_text())
+    assert res["single_scale"]["status"] == base["patterns"]["translate_small"]["single_scale"]["status"] == "Pass"
+    assert res["pyramidal"]["status"] == base["patterns"]["translate_small"]["pyramidal"]["status"] == "Warning"
+    assert abs(res["single_scale"]["metrics"]["epe"] - 0.39136627316474915) < 2e-5  # verification_baseline.json:17
+    # regression gate against the reference's committed baseline passes
+    assert V.compare_against_baseline([res], golden_dir / "verification_baseline.json", 10.0)
+    table = V.generate_markdown_table([res])
+    assert "| translate_small      | ( 0.5,  0.5) | 0.265 | 0.245 | 0.466 | 0.391 | 13.60° | Pass |" in table
+    assert "Testing: translate_small" in capsys.readouterr().out
+
+
+def test_flow_metrics_definitions():
+    import flow_metrics as M
+
+    u = np.array([[1.0, 3.0], [2.0, 2.0]], np.float32)
+    v = np.array([[0.0, 0.0], [1.0, -1.0]], np.float32)
+    m = M.compute_all_metrics(u, v, 2.0, 0.0)
+    assert m["mae_u"] == 0.5 and m["mae_v"] == 0.5
+    assert abs(m["epe"] - 1.0) < 1e-7 and abs(m["rmse"] - 1.0) < 1e-7
+    z = np.zeros((4, 4), np.float32)
+    assert M.angular_error(z, z, 0.0, 0.0) == 0.0
+    mask = np.zeros((2, 2), bool)
+    mask[0, 0] = True
+    assert M.mean_absolute_error(u, v, 2.0, 0.0, mask) == (1.0, 0.0)

@@ -1,0 +1,170 @@
+"""CPU tests: the oracle (oracle/oflk_oracle.c) against golden vectors produced by
+importing the reference (tests/golden/make_golden.py), and against the reference's
+own known-answer file python/verification_baseline.json (tests/golden/ copy).
+
+Bar: bit-exact (sha256 of the float32 bytes after +0.0, or np.array_equal).
+"""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+PATTERNS = ["translate_small", "translate_medium", "translate_large", "translate_vertical", "translate_diagonal",
+            "rotate_small", "rotate_medium", "rotate_large", "zoom_in", "zoom_out", "translate_rotate", "no_motion",
+            "translate_extreme"]
+
+
+def digest(a):
+    a = np.ascontiguousarray(a, np.float32) + np.float32(0.0)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def suite(golden_dir):
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    ref = json.loads((golden_dir / "reference_13patterns.json").read_text())
+    return z, ref
+
+
+@pytest.fixture(scope="module")
+def stage(golden_dir):
+    return np.load(golden_dir / "stage_vectors.npz")
+
+
+def _pair(z, name):
+    return z["frame_0"].astype(np.float32), z[f"frame_1__{name}"].astype(np.float32)
+
+
+def test_pattern_bytes_match_recorded_digests(suite):
+    z, ref = suite
+    assert hashlib.sha256(z["frame_0"].tobytes()).hexdigest() == ref["frame0_sha256"]
+    for name in PATTERNS:
+        assert hashlib.sha256(z[f"frame_1__{name}"].tobytes()).hexdigest() == ref["patterns"][name]["frame1_sha256"]
+
+
+@pytest.mark.parametrize("name", PATTERNS)
+def test_oracle_single_scale_equals_reference(oracle, suite, name):
+    z, ref = suite
+    p, c = _pair(z, name)
+    u, v = oracle.lucas_kanade_single_scale(p, c, 5)
+    r = ref["patterns"][name]["single_scale"]
+    assert digest(u) == r["u_sha256"] and digest(v) == r["v_sha256"]
+
+
+@pytest.mark.parametrize("name", PATTERNS)
+def test_oracle_pyramidal_equals_reference(oracle, suite, name):
+    z, ref = suite
+    p, c = _pair(z, name)
+    u, v, log, runs = oracle.lucas_kanade_pyramidal_ex(p, c, 3, 5, 3)
+    r = ref["patterns"][name]["pyramidal"]
+    assert list(runs) == r["iters_run"]
+    for l, rows in enumerate(r["residual_log"]):
+        # the reference's np.mean(np.abs(d)) values, reproduced exactly (fp32 pairwise, 8192-piece order)
+        np.testing.assert_array_equal(log[l, :len(rows)], np.array(rows, np.float32))
+    assert digest(u) == r["u_sha256"] and digest(v) == r["v_sha256"]
+
+
+def test_no_motion_exits_after_one_iteration(oracle, suite):
+    z, ref = suite
+    p, c = _pair(z, "no_motion")
+    u, v, log, runs = oracle.lucas_kanade_pyramidal_ex(p, c, 3, 5, 3)
+    assert list(runs) == [1, 1, 1] and not u.any() and not v.any()
+
+
+def test_metrics_reproduce_verification_baseline(oracle, suite, golden_dir):
+    """oracle flows + this repo's flow_metrics/mask == the reference's committed known answers"""
+    import flow_metrics
+    import optical_flow_verifier as V
+
+    z, ref = suite
+    base = json.loads((golden_dir / "verification_baseline.json").read_text())["patterns"]
+    worst = 0.0
+    for name in PATTERNS:
+        p, c = _pair(z, name)
+        gt = ref["patterns"][name]["motion"]
+        mask = V.get_test_region_mask(p.shape, name, 80)
+        assert int(mask.sum()) == base[name]["num_test_pixels"]
+        flows = {"single_scale": oracle.lucas_kanade_single_scale(p, c, 5),
+                 "pyramidal": oracle.lucas_kanade_pyramidal(p, c, 3, 5, 3)}
+        for key, (u, v) in flows.items():
+            m = flow_metrics.compute_all_metrics(u, v, gt["dx"], gt["dy"], mask)
+            # exactly what the reference's own metric code gave on the reference's own flows here
+            assert m == ref["patterns"][name][key]["metrics"], (name, key)
+            for k, val in base[name][key]["metrics"].items():
+                worst = max(worst, abs(m[k] - val))
+                assert abs(m[k] - val) <= 2e-5, (name, key, k, m[k], val)
+    assert worst <= 2e-5
+
+
+def test_dense_reference_flow(oracle, suite, golden_dir):
+    z, _ = suite
+    d = np.load(golden_dir / "dense_translate_medium.npz")
+    p, c = _pair(z, "translate_medium")
+    u, v = oracle.lucas_kanade_single_scale(p, c, 5)
+    assert np.array_equal(u, d["single_u"]) and np.array_equal(v, d["single_v"])
+    u, v = oracle.lucas_kanade_pyramidal(p, c, 3, 5, 3)
+    assert np.array_equal(u, d["pyr_u"]) and np.array_equal(v, d["pyr_v"])
+
+
+@pytest.mark.parametrize("tag", ["tile", "noise"])
+def test_stage_vectors(oracle, stage, tag):
+    s = stage
+    p, c = s[f"{tag}__prev"], s[f"{tag}__curr"]
+    Ix, Iy, It = oracle.compute_gradients(p, c)
+    for g, n in ((Ix, "Ix"), (Iy, "Iy"), (It, "It")):
+        assert np.array_equal(g, s[f"{tag}__{n}"]), n
+    for win in (3, 4, 5, 7):
+        u, v = oracle.lucas_kanade_single_scale(p, c, win)
+        assert np.array_equal(u, s[f"{tag}__single_u_w{win}"]) and np.array_equal(v, s[f"{tag}__single_v_w{win}"]), win
+        u2, v2 = oracle.lucas_kanade_from_gradients(Ix, Iy, It, win)
+        assert np.array_equal(u, u2) and np.array_equal(v, v2)
+    for l, a in enumerate(oracle.build_gaussian_pyramid(p, 3)):
+        assert np.array_equal(a, s[f"{tag}__pyr{l}"]), f"pyr{l}"
+    fu, fv = s[f"{tag}__flow_u"], s[f"{tag}__flow_v"]
+    assert np.array_equal(oracle.warp_image(c, fu, fv), s[f"{tag}__warped"])
+    uu, vv = oracle.upsample_flow(fu, fv, s[f"{tag}__up_u"].shape)
+    assert np.array_equal(uu, s[f"{tag}__up_u"]) and np.array_equal(vv, s[f"{tag}__up_v"])
+    u, v, log, runs = oracle.lucas_kanade_pyramidal_ex(p, c, 2, 5, 3)
+    assert list(runs) == list(s[f"{tag}__pyrlk_runs"])
+    assert np.array_equal(u, s[f"{tag}__pyrlk_u"]) and np.array_equal(v, s[f"{tag}__pyrlk_v"])
+    for l in range(2):
+        k = int(runs[l])
+        assert np.array_equal(log[l, :k], s[f"{tag}__pyrlk_log"][l, :k])
+
+
+def test_mean_abs_known_answers(oracle, stage):
+    for n in (25, 4800, 8192, 8200, 76800):
+        assert oracle.mean_abs(stage[f"meanabs__x{n}"]) == stage[f"meanabs__y{n}"][0]
+
+
+def test_rtl_frame_pairs(oracle, golden_dir):
+    """the two 320x240 pairs the reference commits as .mem files for its testbench"""
+    r = np.load(golden_dir / "rtl_frames.npz")
+    for tag in ("natural", "sinusoid"):
+        p, c = r[f"{tag}__frame_00"].astype(np.float32), r[f"{tag}__frame_01"].astype(np.float32)
+        us, vs = oracle.lucas_kanade_single_scale(p, c, 5)
+        up, vp, _, runs = oracle.lucas_kanade_pyramidal_ex(p, c, 3, 5, 3)
+        assert [digest(us), digest(vs), digest(up), digest(vp)] == list(r[f"{tag}__sha"])
+        assert list(runs) == list(r[f"{tag}__runs"])
+        reg = np.s_[105:135, 55:85]
+        ans = r[f"{tag}__answers"]
+        assert np.mean(us[reg]) == ans[0] and np.mean(up[reg]) == ans[2] and float(np.sum(us != 0)) == ans[4]
+
+
+def test_gaussian_weights_are_scipys(oracle):
+    filters = pytest.importorskip("scipy.ndimage._filters")
+    w = filters._gaussian_kernel1d(2.0, 0, 8)
+    assert np.array_equal(oracle.gaussian_kernel1d(2.0), w[8:])
+
+
+def test_oracle_against_scipy_and_numpy_directly(oracle):
+    """third-party arithmetic restated by the oracle, checked against the libraries themselves"""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(11)
+    a = rng.normal(50, 20, (33, 47)).astype(np.float32)
+    assert np.array_equal(oracle.gaussian_filter(a, 2.0), ndi.gaussian_filter(a, sigma=2.0))
+    yy, xx = np.meshgrid(np.linspace(0, 32, 16), np.linspace(0, 46, 23), indexing="ij")
+    assert np.array_equal(oracle.resample_linspace(a, (16, 23)), ndi.map_coordinates(a, [yy, xx], order=1, mode="constant"))
+    x = rng.normal(0, 1, 100000).astype(np.float32)
+    assert oracle.np_sum_f32(x) == np.sum(x) and oracle.mean_abs(x) == np.mean(np.abs(x))
