@@ -227,7 +227,10 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a, 
     Prof pr(plan, s, cls);
     switch (hw) {
         case 1: hipLaunchKernelGGL((k_lk<1, MODE>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_lk<2, MODE>), grid, block, 0, s, a); break;
+        case 2:
+            grid = dim3((a.W + k5TX - 1) / k5TX, (a.H + k5TY - 1) / k5TY, B);
+            hipLaunchKernelGGL((k_lk5<MODE>), grid, dim3(256), 0, s, a);
+            break;
         case 3: hipLaunchKernelGGL((k_lk<3, MODE>), grid, block, 0, s, a); break;
         default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
     }
@@ -489,7 +492,8 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
         }
         const float *lp = (l == L - 1) ? d_prev : p->pyr[l];
         const float *lc = (l == L - 1) ? d_curr : p->pyr[l] + (size_t)B * n;
-        const int nblk = ((w + kTX - 1) / kTX) * ((h + kTY - 1) / kTY);
+        const int nblk = p->hw == 2 ? ((w + k5TX - 1) / k5TX) * ((h + k5TY - 1) / k5TY)
+                                    : ((w + kTX - 1) / kTX) * ((h + kTY - 1) / kTY);
         for (int k = 0; k < K; k++) {
             LkArgs a{};
             a.prev = lp; a.curr = lc;

@@ -381,6 +381,332 @@ __global__ __launch_bounds__(kLkThreads) void k_lk(LkArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// K1/K7 specialised for the 5x5 window (window_size 4 or 5): the hot kernel.
+//
+// Tile 64 x 32 per 256-thread block, each thread 2 (x) x 4 (y) outputs.
+//
+// Exact window sums with fewer adds.  NumPy sums the 25 products a[0..24]
+// (row-major) as r[j] = (a[j] + a[j+8]) + a[j+16], j = 0..7, then
+// ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) + a[24].  With a[5*row+col] =
+// P[y-2+row][x-2+col] several r's of neighbouring windows are THE SAME three
+// products added in THE SAME order, hence bit-identical:
+//     r1(x,y) = r0(x+1,y)   r3(x,y) = r2(x+1,y)   r5(x,y) = r0(x,y+1)
+//     r6(x,y) = r0(x+1,y+1) r7(x,y) = r2(x,y+1)
+// so a 2x4 output patch needs 15 r0's, 14 r2's and 8 r4's (74 adds) instead of
+// 64 r's (128 adds); tree and tail are per output.  No rounding is changed.
+//
+// LDS layout: products interleaved as float2 {Ix*Ix, Iy*Iy}, float2 {Ix*Iy, Ix*It}
+// and float {Iy*It}, so the sums of two planes ride one v_pk_add_f32.  The
+// frame-average / It staging tiles alias the product planes (gradients wait in
+// registers across the barrier).
+// ---------------------------------------------------------------------------
+constexpr int k5TX = 64;
+constexpr int k5TY = 32;
+
+// Optimisation fence on a value: the compiler must have it computed here and may not
+// sink its computation past later fences (keeps the row-streaming order, and with it
+// the register footprint, of the window-sum code).  No instruction is emitted.
+__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(float2 &x)
+{
+    double d = __builtin_bit_cast(double, x);
+    asm volatile("" : "+v"(d));
+    x = __builtin_bit_cast(float2, d);
+}
+
+template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
+template <> __device__ __forceinline__ float2 zero_of<float2>() { return make_float2(0.0f, 0.0f); }
+
+// Window sums of a 2 (x) by NY (y) output patch, streaming the NY+4 product rows
+// top to bottom: at most three rows and three output rows' partial r's are live.
+// `load_row(i, row)` fills row[0..5] with products P[y0-2+i][x0-2 .. x0+3].
+template <typename T, int NY, typename LoadRow>
+__device__ __forceinline__ void patch5_sums(LoadRow load_row, T (&out)[NY][2])
+{
+    T R0[NY + 1][3], R2[NY + 1][3], R4[NY][2];
+    T w[NY + 4][6];
+    load_row(0, w[0]);
+#pragma unroll
+    for (int i = 0; i < NY + 4; i++) {
+        // one row is prefetched ahead of the arithmetic; the fence keeps the compiler
+        // from hoisting every LDS read to the top (which would need ~250 VGPRs)
+        if (i + 1 < NY + 4) load_row(i + 1, w[i + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i >= 1 && i - 1 <= NY) {
+            const int oy = i - 1;  // r0 family, first add: a[0] + a[8]
+#pragma unroll
+            for (int x = 0; x < 3; x++) R0[oy][x] = w[i - 1][x] + w[i][x + 3];
+        }
+        if (i >= 2 && i - 2 <= NY) {
+            const int oy = i - 2;  // r2 and r4 families, first add: a[2] + a[10], a[4] + a[12]
+#pragma unroll
+            for (int x = 0; x < 3; x++)
+                if (oy < NY || x < 2) R2[oy][x] = w[i - 2][x + 2] + w[i][x];
+            if (oy < NY) {
+#pragma unroll
+                for (int x = 0; x < 2; x++) R4[oy][x] = w[i - 2][x + 4] + w[i][x + 2];
+            }
+        }
+        if (i >= 3 && i - 3 <= NY) {
+            const int oy = i - 3;  // second add: + a[16], + a[18]
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                R0[oy][x] = R0[oy][x] + w[i][x + 1];
+                if (oy < NY || x < 2) R2[oy][x] = R2[oy][x] + w[i][x + 3];
+            }
+        }
+        if (i >= 4) {
+            const int oy = i - 4;  // + a[20]; the window of output row oy is complete
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                R4[oy][x] = R4[oy][x] + w[i][x];
+                T lo = (R0[oy][x] + R0[oy][x + 1]) + (R2[oy][x] + R2[oy][x + 1]);
+                T hi = (R4[oy][x] + R0[oy + 1][x]) + (R0[oy + 1][x + 1] + R2[oy + 1][x]);
+                T res = lo + hi;
+                res = res + w[i][x + 4];           // a[24]
+                out[oy][x] = zero_of<T>() + res;   // np.sum starts from the identity 0
+                pin(out[oy][x]);
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lk5(LkArgs a)
+{
+    constexpr int HW = 2, R = 3;
+    constexpr int AH = k5TY + 2 * R, AW = k5TX + 2 * R;  // 38 x 70 frame-average tile
+    constexpr int AS = AW + 1;
+    constexpr int PH = k5TY + 2 * HW, PW = k5TX + 2 * HW;  // 36 x 68 product tile
+    constexpr int NG = (PH * PW + 255) / 256;              // gradient pixels per thread (10)
+
+    // one LDS block: [PA float2 | PB float2 | PC float]; avg and It alias its start
+    __shared__ __attribute__((aligned(16))) float s_mem[PH * PW * 5];
+    float2 *s_pa = reinterpret_cast<float2 *>(s_mem);
+    float2 *s_pb = reinterpret_cast<float2 *>(s_mem + PH * PW * 2);
+    float *s_pc = s_mem + PH * PW * 4;
+    float *s_avg = s_mem;                 // AH*AS = 2698 floats
+    float *s_it = s_mem + AH * AS + 2;    // PH*PW = 2448 floats (ends at 5148 < 12240)
+    static_assert(AH * AS + 2 + PH * PW <= PH * PW * 5, "staging tiles must fit the product planes");
+
+    const int b = blockIdx.z;
+    int sel = 0;
+    if (MODE == MODE_ITER) {
+        if (a.done[b]) return;
+        sel = a.sel[b];
+    }
+    const int H = a.H, W = a.W;
+    const size_t plane = (size_t)H * (size_t)W;
+    const float *__restrict__ prev = a.prev + (size_t)b * plane;
+    const float *__restrict__ curr = a.curr + (size_t)b * plane;
+    const int x0 = blockIdx.x * k5TX, y0 = blockIdx.y * k5TY;
+    const int tid = threadIdx.x;
+
+    float gix[NG], giy[NG], git[NG];
+    if (MODE == MODE_GRADS) {
+        const float *__restrict__ gtp = a.aux + (size_t)b * plane;
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            int e = tid + k * 256;
+            int r = e / PW, c = e - r * PW;
+            int gy = y0 - HW + r, gx = x0 - HW + c;
+            bool in = e < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            int i = in ? gy * W + gx : 0;
+            gix[k] = in ? prev[i] : 0.0f;
+            giy[k] = in ? curr[i] : 0.0f;
+            git[k] = in ? gtp[i] : 0.0f;
+        }
+    } else {
+        // ---- stage 1: second frame (warped if ITER), frame average, It -------
+        const float *__restrict__ fu_in = nullptr;
+        const float *__restrict__ fv_in = nullptr;
+        if (MODE == MODE_ITER) {
+            fu_in = a.fu[sel] + (size_t)b * plane;
+            fv_in = a.fv[sel] + (size_t)b * plane;
+        }
+        for (int e = tid; e < AH * AW; e += 256) {
+            int r = e / AW, c = e - r * AW;
+            int gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
+            int gx = min(max(x0 - R + c, 0), W - 1);
+            int i = gy * W + gx;
+            float p = prev[i];
+            float q;
+            if (MODE == MODE_ITER) {
+                double xs = (double)gx + (double)fu_in[i];  // lucas_kanade_pyramidal.py:88-89
+                double ys = (double)gy + (double)fv_in[i];
+                q = bilinear_f64(curr, H, W, ys, xs);
+            } else {
+                q = curr[i];
+            }
+            float sum = p + q;
+            s_avg[r * AS + c] = sum * 0.5f;
+            if (r >= 1 && r < AH - 1 && c >= 1 && c < AW - 1) s_it[(r - 1) * PW + (c - 1)] = p - q;
+        }
+        __syncthreads();
+        // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            int e = tid + k * 256;
+            if (e >= PH * PW) e = PH * PW - 1;  // tail threads recompute the last cell
+            int r = e / PW, c = e - r * PW;
+            const float *ap = &s_avg[(r + 1) * AS + (c + 1)];
+            float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
+            float a_0m = ap[-1], a_0p = ap[1];
+            float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
+            float ix = a_pp * -0.125f;
+            ix = fmaf(a_pm, 0.125f, ix);
+            ix = fmaf(a_0p, -0.25f, ix);
+            ix = fmaf(a_0m, 0.25f, ix);
+            ix = fmaf(a_mp, -0.125f, ix);
+            ix = fmaf(a_mm, 0.125f, ix);
+            float iy = a_pp * -0.125f;
+            iy = fmaf(a_p0, -0.25f, iy);
+            iy = fmaf(a_pm, -0.125f, iy);
+            iy = fmaf(a_mp, 0.125f, iy);
+            iy = fmaf(a_m0, 0.25f, iy);
+            iy = fmaf(a_mm, 0.125f, iy);
+            gix[k] = ix;
+            giy[k] = iy;
+            git[k] = s_it[e];
+        }
+        __syncthreads();  // everyone is done reading avg / It: the planes may overwrite them
+    }
+    // ---- products into the interleaved planes --------------------------------
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        int e = tid + k * 256;
+        if (e < PH * PW) {
+            float ix = gix[k], iy = giy[k], it = git[k];
+            s_pa[e] = make_float2(ix * ix, iy * iy);
+            s_pb[e] = make_float2(ix * iy, ix * it);
+            s_pc[e] = iy * it;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 3: shared-r window sums (pk over plane pairs), solve, write -----
+    // thread = 2 (x) by 4 (y) outputs; a half-wave spans one tile row, so the
+    // 16-byte LDS reads of 32 adjacent lanes are contiguous (conflict-free)
+    constexpr int NY = 4;
+    const int tx = tid & 31, ty = tid >> 5;
+    float2 sA[NY][2], sB[NY][2];
+    float sC[NY][2];
+    {
+        const float2 *base = &s_pa[(NY * ty) * PW + 2 * tx];
+        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(base + i * PW);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float4 q = r4[j];
+                row[2 * j] = make_float2(q.x, q.y);
+                row[2 * j + 1] = make_float2(q.z, q.w);
+            }
+        }, sA);
+    }
+    {
+        const float2 *base = &s_pb[(NY * ty) * PW + 2 * tx];
+        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(base + i * PW);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float4 q = r4[j];
+                row[2 * j] = make_float2(q.x, q.y);
+                row[2 * j + 1] = make_float2(q.z, q.w);
+            }
+        }, sB);
+    }
+    {
+        const float *base = &s_pc[(NY * ty) * PW + 2 * tx];
+        patch5_sums<float, NY>([&](int i, float (&row)[6]) {
+            const float2 *r2 = reinterpret_cast<const float2 *>(base + i * PW);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float2 q = r2[j];
+                row[2 * j] = q.x;
+                row[2 * j + 1] = q.y;
+            }
+        }, sC);
+    }
+
+    const int gxb = x0 + 2 * tx;
+    double su = 0.0, sv = 0.0;
+    float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
+    float *__restrict__ ov = a.fv[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
+    const float *__restrict__ iu = MODE == MODE_ITER ? a.fu[sel] + (size_t)b * plane : nullptr;
+    const float *__restrict__ iv = MODE == MODE_ITER ? a.fv[sel] + (size_t)b * plane : nullptr;
+#pragma unroll
+    for (int oy = 0; oy < NY; oy++) {
+        const int gy = y0 + NY * ty + oy;
+        float du[2], dv[2];
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            float u, v;
+            lk_solve(sA[oy][o].x, sA[oy][o].y, sB[oy][o].x, sB[oy][o].y, sC[oy][o], u, v);
+            int gx = gxb + o;
+            bool interior = gy >= HW && gy < H - HW && gx >= HW && gx < W - HW;
+            du[o] = interior ? u : 0.0f;
+            dv[o] = interior ? v : 0.0f;
+            if (MODE == MODE_ITER && gy < H && gx < W) {
+                su += (double)fabsf(du[o]);
+                sv += (double)fabsf(dv[o]);
+            }
+        }
+        if (gy < H && gxb < W) {
+            int i = gy * W + gxb;
+            if (((W & 1) == 0) && gxb + 1 < W) {
+                float2 ru = make_float2(du[0], du[1]);
+                float2 rv = make_float2(dv[0], dv[1]);
+                if (MODE == MODE_ITER) {
+                    // flow += d (lucas_kanade_pyramidal.py:209-210)
+                    float2 pu = *reinterpret_cast<const float2 *>(iu + i);
+                    float2 pv = *reinterpret_cast<const float2 *>(iv + i);
+                    ru.x = pu.x + ru.x; ru.y = pu.y + ru.y;
+                    rv.x = pv.x + rv.x; rv.y = pv.y + rv.y;
+                }
+                *reinterpret_cast<float2 *>(ou + i) = ru;
+                *reinterpret_cast<float2 *>(ov + i) = rv;
+            } else {
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    if (gxb + o < W) {
+                        float ru = du[o], rv = dv[o];
+                        if (MODE == MODE_ITER) {
+                            ru = iu[i + o] + ru;
+                            rv = iv[i + o] + rv;
+                        }
+                        ou[i + o] = ru;
+                        ov[i + o] = rv;
+                    }
+                }
+            }
+        }
+    }
+
+    if (MODE == MODE_ITER) {
+        __shared__ double s_red[2][4];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            su += __shfl_down(su, off, 64);
+            sv += __shfl_down(sv, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            s_red[0][tid >> 6] = su;
+            s_red[1][tid >> 6] = sv;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double tu = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+            double tv = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+            size_t nblk = (size_t)gridDim.x * gridDim.y;
+            size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            a.partial[((size_t)b * nblk + blk) * 2 + 0] = tu;
+            a.partial[((size_t)b * nblk + blk) * 2 + 1] = tv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K6: per-pair residual means, log, convergence flag
 // (lucas_kanade_pyramidal.py:213-223).  One block per pair; fixed summation
 // order, fp64.  The reference's np.mean is an fp32 pairwise sum; the two agree
