@@ -153,9 +153,10 @@ int window_hw(int window_size, int *hw)
 
 // ---- kernel classes for the per-kernel event timing --------------------------
 enum KClass { KC_LK_SINGLE = 0, KC_LK_ITER, KC_LK_ITER_FINEST, KC_FINALIZE, KC_BLUR, KC_RESAMPLE,
-              KC_UPSAMPLE, KC_EXPORT, KC_MEMSET, KC_COUNT };
+              KC_UPSAMPLE, KC_EXPORT, KC_MEMSET, KC_PYR_FUSED, KC_COUNT };
 const char *kClassNames[KC_COUNT] = {"lk_single", "lk_iter", "lk_iter_finest", "finalize", "blur",
-                                     "pyr_resample", "flow_upsample", "export_fixup", "memset"};
+                                     "pyr_resample", "flow_upsample", "export_fixup", "memset",
+                                     "pyr_down_fused"};
 
 }  // namespace
 
@@ -240,10 +241,44 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a, 
 
 inline dim3 grid2d(int W, int H, int n) { return dim3((W + 63) / 64, (H + 3) / 4, n); }
 
+// does every 32 x 16 coarse tile's source span fit the fused kernel's LDS tile?
+// (exactly the index arithmetic of k_pyr_down, evaluated for each tile row / column)
+bool pyr_fused_fits(int h, int w, int ho, int wo, const GaussW &g)
+{
+    if (g.radius != 8) return false;
+    auto span_ok = [](int S, int T, int tile, int cap) {
+        Linspace l = make_linspace(S, T);
+        auto at = [&](int i) { return T <= 1 ? 0.0 : (i == T - 1 ? l.last : (double)i * l.step); };
+        for (int t0 = 0; t0 < T; t0 += tile) {
+            int last = std::min(t0 + tile, T) - 1;
+            int lo = (int)std::floor(at(t0));
+            if (t0 + tile >= T) lo = std::min(lo, std::max(S - 2, 0));
+            int hi = std::min((int)std::floor(at(last)) + 1, S - 1);
+            if (hi - lo + 1 > cap) return false;
+        }
+        return true;
+    };
+    return span_ok(h, ho, kPTH, kPBH) && span_ok(w, wo, kPTW, kPBW);
+}
+
 // gaussian blur + linspace resample of `nimg` images: in [nimg][h][w] -> out [nimg][ho][wo]
 int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const float *in, float *out,
                     float *tmpA, float *tmpB, int nimg, int h, int w, int ho, int wo)
 {
+    if (pyr_fused_fits(h, w, ho, wo, gauss)) {
+        PyrArgs a{};
+        a.in = in;
+        a.out = out;
+        a.H = h; a.W = w; a.Ho = ho; a.Wo = wo;
+        a.ly = make_linspace(h, ho);
+        a.lx = make_linspace(w, wo);
+        for (int k = 0; k <= 8; k++) a.w[k] = gauss.w[k];
+        dim3 grid((wo + kPTW - 1) / kPTW, (ho + kPTH - 1) / kPTH, nimg);
+        Prof pr(plan, s, KC_PYR_FUSED);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return OFLK_OK;
+    }
     {
         Prof pr(plan, s, KC_BLUR);
         hipLaunchKernelGGL((k_blur<0>), grid2d(w, h, nimg), dim3(256), 0, s, in, tmpA, h, w, gauss);

@@ -68,6 +68,19 @@ __device__ __forceinline__ float bilinear_apply(const float *__restrict__ img, c
     return (float)acc;
 }
 
+// same accumulation with the four taps already loaded
+__device__ __forceinline__ float bilinear_finish(const BilinearTaps &t, float p00, float p01, float p10,
+                                                 float p11)
+{
+    if (!t.inside) return 0.0f;
+    double acc = 0.0, c;
+    c = (double)p00; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
+    c = (double)p01; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
+    c = (double)p10; c = c * t.wy1; c = c * t.wx0; acc = acc + c;
+    c = (double)p11; c = c * t.wy1; c = c * t.wx1; acc = acc + c;
+    return (float)acc;
+}
+
 __device__ __forceinline__ float bilinear_f64(const float *__restrict__ img, int H, int W, double y,
                                               double x)
 {
@@ -400,8 +413,15 @@ __global__ __launch_bounds__(kLkThreads) void k_lk(LkArgs a)
 // frame-average / It staging tiles alias the product planes (gradients wait in
 // registers across the barrier).
 // ---------------------------------------------------------------------------
+#ifndef OFLK_NY
+#define OFLK_NY 4
+#endif
+#ifndef OFLK_BATCH
+#define OFLK_BATCH 4
+#endif
+constexpr int k5NY = OFLK_NY;      // output rows per thread
 constexpr int k5TX = 64;
-constexpr int k5TY = 32;
+constexpr int k5TY = 8 * k5NY;     // 8 thread rows x NY
 
 // Optimisation fence on a value: the compiler must have it computed here and may not
 // sink its computation past later fences (keeps the row-streaming order, and with it
@@ -525,23 +545,65 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             fu_in = a.fu[sel] + (size_t)b * plane;
             fv_in = a.fv[sel] + (size_t)b * plane;
         }
-        for (int e = tid; e < AH * AW; e += 256) {
-            int r = e / AW, c = e - r * AW;
-            int gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
-            int gx = min(max(x0 - R + c, 0), W - 1);
-            int i = gy * W + gx;
-            float p = prev[i];
-            float q;
-            if (MODE == MODE_ITER) {
-                double xs = (double)gx + (double)fu_in[i];  // lucas_kanade_pyramidal.py:88-89
-                double ys = (double)gy + (double)fv_in[i];
-                q = bilinear_f64(curr, H, W, ys, xs);
-            } else {
-                q = curr[i];
+        // Batches of BATCH cells per thread: all coalesced loads of a batch are issued
+        // together, then all bilinear gathers, so a wave keeps 4*BATCH gathers in flight
+        // instead of walking one dependent load chain per cell.
+        constexpr int NE = (AH * AW + 255) / 256;
+        constexpr int BATCH = OFLK_BATCH;
+#pragma unroll
+        for (int k0 = 0; k0 < NE; k0 += BATCH) {
+            float p[BATCH], q[BATCH];
+            int lo[BATCH], li[BATCH];
+            bool live[BATCH], inner[BATCH];
+            BilinearTaps tp[BATCH];
+            float t00[BATCH], t01[BATCH], t10[BATCH], t11[BATCH];
+            float uu[BATCH], vv[BATCH];
+            int gxs[BATCH], gys[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                int e = tid + (k0 + j) * 256;
+                live[j] = (k0 + j < NE) && e < AH * AW;
+                if (!live[j]) e = AH * AW - 1;
+                int r = e / AW, c = e - r * AW;
+                int gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
+                int gx = min(max(x0 - R + c, 0), W - 1);
+                int i = gy * W + gx;
+                lo[j] = r * AS + c;
+                li[j] = (r - 1) * PW + (c - 1);
+                inner[j] = r >= 1 && r < AH - 1 && c >= 1 && c < AW - 1;
+                gxs[j] = gx;
+                gys[j] = gy;
+                p[j] = prev[i];
+                if (MODE == MODE_ITER) {
+                    uu[j] = fu_in[i];
+                    vv[j] = fv_in[i];
+                } else {
+                    q[j] = curr[i];
+                }
             }
-            float sum = p + q;
-            s_avg[r * AS + c] = sum * 0.5f;
-            if (r >= 1 && r < AH - 1 && c >= 1 && c < AW - 1) s_it[(r - 1) * PW + (c - 1)] = p - q;
+            if (MODE == MODE_ITER) {
+#pragma unroll
+                for (int j = 0; j < BATCH; j++) {
+                    double xs = (double)gxs[j] + (double)uu[j];  // lucas_kanade_pyramidal.py:88-89
+                    double ys = (double)gys[j] + (double)vv[j];
+                    tp[j] = bilinear_taps(H, W, ys, xs);
+                    t00[j] = curr[tp[j].i00];
+                    t01[j] = curr[tp[j].i01];
+                    t10[j] = curr[tp[j].i10];
+                    t11[j] = curr[tp[j].i11];
+                }
+#pragma unroll
+                for (int j = 0; j < BATCH; j++)
+                    q[j] = bilinear_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                if (live[j]) {
+                    float sum = p[j] + q[j];
+                    s_avg[lo[j]] = sum * 0.5f;
+                    if (inner[j]) s_it[li[j]] = p[j] - q[j];
+                }
+            }
         }
         __syncthreads();
         // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
@@ -588,7 +650,7 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
     // ---- stage 3: shared-r window sums (pk over plane pairs), solve, write -----
     // thread = 2 (x) by 4 (y) outputs; a half-wave spans one tile row, so the
     // 16-byte LDS reads of 32 adjacent lanes are contiguous (conflict-free)
-    constexpr int NY = 4;
+    constexpr int NY = k5NY;
     const int tx = tid & 31, ty = tid >> 5;
     float2 sA[NY][2], sB[NY][2];
     float sC[NY][2];
@@ -835,6 +897,144 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
         float r = bilinear_apply(a.in[p] + selofs + (size_t)img * ip, t);
         if (a.apply_scale) r = r * a.scale[p];
         a.out[p][(size_t)img * op + (size_t)i * a.Wo + j] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 fused: one pyramid step (gaussian_filter sigma = 2, radius 8, then the
+// linspace bilinear downsample; lucas_kanade_pyramidal.py:46-59) in one kernel.
+// A block produces a 32 x 16 tile of the coarse level:
+//   A  input rows/cols (reflect-extended) needed by the tile       -> LDS
+//   B  vertical 17-tap pass, fp64 accumulation, fp32 store (SciPy stores fp32
+//      between axes)                                                -> LDS
+//   C  horizontal 17-tap pass on that, fp64 accumulation, fp32      -> LDS
+//   D  bilinear sampling of the blurred tile in fp64                -> HBM
+// Same operation order as the unfused k_blur<0>, k_blur<1>, k_resample chain;
+// the blurred image never goes to HBM (algorithmic traffic: read 4 B per fine
+// pixel, write 4 B per coarse pixel).
+// The host checks that a tile's source span fits the static LDS tile
+// (pyr_fused_fits) and otherwise uses the unfused chain.
+// ---------------------------------------------------------------------------
+constexpr int kPTW = 32, kPTH = 16;          // coarse outputs per block
+constexpr int kPBW = 2 * kPTW + 2;           // blurred cols a tile may need (66)
+constexpr int kPBH = 2 * kPTH + 2;           // blurred rows (34)
+constexpr int kPIW = kPBW + 16;              // input cols incl. radius-8 halo (82)
+constexpr int kPIH = kPBH + 16;              // input rows (50)
+constexpr int kPVS = kPIW + 1;               // row stride of the vertical-pass tile (odd)
+constexpr int kPHS = kPBW + 1;               // row stride of the blurred tile
+
+struct PyrArgs {
+    const float *in;   // [nimg][H][W]
+    float *out;        // [nimg][Ho][Wo]
+    int H, W, Ho, Wo;
+    Linspace ly, lx;
+    double w[9];       // gaussian weights, w[k] at distance k
+};
+
+__global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
+{
+    __shared__ float s_in[kPIH * kPIW];   // stage A; reused for the blurred tile (stage C output)
+    __shared__ float s_v[kPBH * kPVS];
+    float *s_h = s_in;
+    static_assert(kPBH * kPHS <= kPIH * kPIW, "blurred tile must fit the input tile's storage");
+
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const size_t ip = (size_t)H * (size_t)W, op = (size_t)a.Ho * (size_t)a.Wo;
+    const float *__restrict__ src = a.in + (size_t)blockIdx.z * ip;
+    const int j0 = blockIdx.x * kPTW, i0 = blockIdx.y * kPTH;
+    // first blurred row / column any tap of this tile touches (a sample that lands
+    // exactly on the last row reads the mirrored row H-2 with weight 0)
+    int ylo = (int)floor(linspace_at(a.ly, i0));
+    int xlo = (int)floor(linspace_at(a.lx, j0));
+    if (i0 + kPTH >= a.Ho) ylo = min(ylo, max(H - 2, 0));
+    if (j0 + kPTW >= a.Wo) xlo = min(xlo, max(W - 2, 0));
+
+    // ---- A: input tile, reflect-extended ------------------------------------
+    for (int e = tid; e < kPIH * kPIW; e += 256) {
+        int r = e / kPIW, c = e - r * kPIW;
+        int gy = reflect_idx(ylo - 8 + r, H);
+        int gx = reflect_idx(xlo - 8 + c, W);
+        s_in[e] = src[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+
+    // ---- B: vertical pass; thread = one column, 12 consecutive rows ----------
+    {
+        constexpr int RS = 12;                       // rows per thread (3 segments cover 34)
+        const int col = tid % kPIW, seg = tid / kPIW;
+        if (seg < 3) {
+            float win[RS + 16];
+#pragma unroll
+            for (int k = 0; k < RS + 16; k++) {
+                int r = min(seg * RS + k, kPIH - 1);
+                win[k] = s_in[r * kPIW + col];
+            }
+#pragma unroll
+            for (int o = 0; o < RS; o++) {
+                double t = (double)win[o + 8] * a.w[0];
+#pragma unroll
+                for (int k = 8; k >= 1; k--) {
+                    double sgm = (double)win[o + 8 - k] + (double)win[o + 8 + k];
+                    double m = sgm * a.w[k];
+                    t = t + m;
+                }
+                int r = seg * RS + o;
+                if (r < kPBH) s_v[r * kPVS + col] = (float)t;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- C: horizontal pass; thread = one row, 11 consecutive columns --------
+    {
+        constexpr int CS = 11;                       // cols per thread (6 segments cover 66)
+        const int row = tid % kPBH, seg = tid / kPBH;
+        if (seg < 6) {
+            float win[CS + 16];
+#pragma unroll
+            for (int k = 0; k < CS + 16; k++) win[k] = s_v[row * kPVS + seg * CS + k];
+#pragma unroll
+            for (int o = 0; o < CS; o++) {
+                double t = (double)win[o + 8] * a.w[0];
+#pragma unroll
+                for (int k = 8; k >= 1; k--) {
+                    double sgm = (double)win[o + 8 - k] + (double)win[o + 8 + k];
+                    double m = sgm * a.w[k];
+                    t = t + m;
+                }
+                s_h[row * kPHS + seg * CS + o] = (float)t;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- D: bilinear sampling from the blurred tile ----------------------------
+    float *__restrict__ dst = a.out + (size_t)blockIdx.z * op;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        int o = tid + k * 256;
+        int i = i0 + o / kPTW, j = j0 + o % kPTW;
+        if (i >= a.Ho || j >= a.Wo) continue;
+        double y = linspace_at(a.ly, i), x = linspace_at(a.lx, j);
+        float r = 0.0f;
+        if (!(y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1))) {
+            double fy = floor(y), fx = floor(x);
+            int y0 = (int)fy, x0 = (int)fx;
+            double wy0 = 1.0 - (y - fy), wx0 = 1.0 - (x - fx);
+            double wy1 = 1.0 - wy0, wx1 = 1.0 - wx0;
+            int y1 = (y0 + 1 < H) ? y0 + 1 : (H > 1 ? H - 2 : 0);
+            int x1 = (x0 + 1 < W) ? x0 + 1 : (W > 1 ? W - 2 : 0);
+            const float *r0 = s_h + (y0 - ylo) * kPHS - xlo;
+            const float *r1 = s_h + (y1 - ylo) * kPHS - xlo;
+            double acc = 0.0, c;
+            c = (double)r0[x0]; c = c * wy0; c = c * wx0; acc = acc + c;
+            c = (double)r0[x1]; c = c * wy0; c = c * wx1; acc = acc + c;
+            c = (double)r1[x0]; c = c * wy1; c = c * wx0; acc = acc + c;
+            c = (double)r1[x1]; c = c * wy1; c = c * wx1; acc = acc + c;
+            r = (float)acc;
+        }
+        dst[(size_t)i * a.Wo + j] = r;
     }
 }
 
