@@ -221,16 +221,21 @@ struct Prof {
 };
 
 template <int MODE>
-int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a, int B)
+int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_in, int B)
 {
+    LkArgs a = a_in;
+    a.B = B;
     dim3 grid((a.W + kTX - 1) / kTX, (a.H + kTY - 1) / kTY, B);
     dim3 block(kLkThreads);
     Prof pr(plan, s, cls);
     switch (hw) {
         case 1: hipLaunchKernelGGL((k_lk<1, MODE>), grid, block, 0, s, a); break;
         case 2:
-            grid = dim3((a.W + k5TX - 1) / k5TX, (a.H + k5TY - 1) / k5TY, B);
-            hipLaunchKernelGGL((k_lk5<MODE>), grid, dim3(256), 0, s, a);
+            grid = dim3((unsigned)(((a.W + k5TX - 1) / k5TX) * ((a.H + k5TY - 1) / k5TY) * B));
+            if ((a.W & 3) == 0)
+                hipLaunchKernelGGL((k_lk5<MODE, true>), grid, dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((k_lk5<MODE, false>), grid, dim3(256), 0, s, a);
             break;
         case 3: hipLaunchKernelGGL((k_lk<3, MODE>), grid, block, 0, s, a); break;
         default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);

@@ -176,6 +176,7 @@ struct LkArgs {
     const int *sel;     // ITER: per pair, which of fu[]/fv[] holds the current flow
     const int *done;    // ITER: per pair, level already converged -> skip
     int H, W;
+    int B;              // frame pairs in the launch (k_lk5 decodes pair/tile from a 1-D grid)
 };
 
 template <int HW, int MODE>
@@ -419,6 +420,24 @@ __global__ __launch_bounds__(kLkThreads) void k_lk(LkArgs a)
 #ifndef OFLK_BATCH
 #define OFLK_BATCH 4
 #endif
+// XCD-aware tile order (speed only, never correctness).  Workgroups of a 1-D grid are
+// dealt round-robin over the 8 XCDs (ids i and i+8 share an XCD, each with its own L2).
+// Giving XCD x the contiguous tile range [x*chunk, (x+1)*chunk) makes x- and
+// y-adjacent tiles, which share halo cache lines, meet in one L2 at about the same time.
+__device__ __forceinline__ int xcd_tile_index(int bid, int ntiles)
+{
+    constexpr int NXCD = 8;
+    const int chunk = (ntiles + NXCD - 1) / NXCD;
+    const int full = ntiles - (NXCD - 1) * chunk;   // tiles in the last XCD's range (may be < chunk)
+    // ids below NXCD*full interleave all 8 ranges; the rest only the first 7
+    if (bid < NXCD * full || full < 0) {
+        if (full < 0) return bid;                   // tiny grids: plain order
+        return (bid % NXCD) * chunk + bid / NXCD;
+    }
+    const int r = bid - NXCD * full;
+    return (r % (NXCD - 1)) * chunk + full + r / (NXCD - 1);
+}
+
 constexpr int k5NY = OFLK_NY;      // output rows per thread
 constexpr int k5TX = 64;
 constexpr int k5TY = 8 * k5NY;     // 8 thread rows x NY
@@ -492,35 +511,49 @@ __device__ __forceinline__ void patch5_sums(LoadRow load_row, T (&out)[NY][2])
     }
 }
 
-template <int MODE>
+// Stage 1 works on groups of four horizontally adjacent cells: the staging tiles are
+// 38 rows x 72 columns starting at (y0-3, x0-4), so with W % 4 == 0 every group is one
+// aligned 16-byte load per plane (a group lies entirely inside or entirely outside the
+// image).  Other widths take the VEC = false instantiation (cell-by-cell loads).
+constexpr int k5GW = 18;                 // groups per staging row
+constexpr int k5AS = 4 * k5GW;           // 72 staging columns
+
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
 {
     constexpr int HW = 2, R = 3;
-    constexpr int AH = k5TY + 2 * R, AW = k5TX + 2 * R;  // 38 x 70 frame-average tile
-    constexpr int AS = AW + 1;
-    constexpr int PH = k5TY + 2 * HW, PW = k5TX + 2 * HW;  // 36 x 68 product tile
+    constexpr int AH = k5TY + 2 * R;                       // 38 staging rows (y0-3 ..)
+    constexpr int AS = k5AS;                               // 72 staging columns (x0-4 ..)
+    constexpr int PH = k5TY + 2 * HW, PW = k5TX + 2 * HW;  // 36 x 68 product tile (y0-2, x0-2)
     constexpr int NG = (PH * PW + 255) / 256;              // gradient pixels per thread (10)
+    constexpr int NGRP = AH * k5GW;                        // 684 groups of 4 cells
+    constexpr int NV = (NGRP + 255) / 256;                 // groups per thread (3)
 
     // one LDS block: [PA float2 | PB float2 | PC float]; avg and It alias its start
     __shared__ __attribute__((aligned(16))) float s_mem[PH * PW * 5];
     float2 *s_pa = reinterpret_cast<float2 *>(s_mem);
     float2 *s_pb = reinterpret_cast<float2 *>(s_mem + PH * PW * 2);
     float *s_pc = s_mem + PH * PW * 4;
-    float *s_avg = s_mem;                 // AH*AS = 2698 floats
-    float *s_it = s_mem + AH * AS + 2;    // PH*PW = 2448 floats (ends at 5148 < 12240)
-    static_assert(AH * AS + 2 + PH * PW <= PH * PW * 5, "staging tiles must fit the product planes");
+    float *s_avg = s_mem;              // AH*AS = 2736 floats
+    float *s_it = s_mem + AH * AS;     // another 2736 floats
+    static_assert(2 * AH * AS <= PH * PW * 5, "staging tiles must fit the product planes");
 
-    const int b = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
+    const int tiles_per_pair = tiles_x * tiles_y;
+    const int tile = xcd_tile_index(blockIdx.x, tiles_per_pair * a.B);
+    const int b = tile / tiles_per_pair;
+    const int tile_in_pair = tile - b * tiles_per_pair;
+    const int tile_y = tile_in_pair / tiles_x, tile_x = tile_in_pair - tile_y * tiles_x;
     int sel = 0;
     if (MODE == MODE_ITER) {
         if (a.done[b]) return;
         sel = a.sel[b];
     }
-    const int H = a.H, W = a.W;
     const size_t plane = (size_t)H * (size_t)W;
     const float *__restrict__ prev = a.prev + (size_t)b * plane;
     const float *__restrict__ curr = a.curr + (size_t)b * plane;
-    const int x0 = blockIdx.x * k5TX, y0 = blockIdx.y * k5TY;
+    const int x0 = tile_x * k5TX, y0 = tile_y * k5TY;
     const int tid = threadIdx.x;
 
     float gix[NG], giy[NG], git[NG];
@@ -545,63 +578,129 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             fu_in = a.fu[sel] + (size_t)b * plane;
             fv_in = a.fv[sel] + (size_t)b * plane;
         }
-        // Batches of BATCH cells per thread: all coalesced loads of a batch are issued
-        // together, then all bilinear gathers, so a wave keeps 4*BATCH gathers in flight
-        // instead of walking one dependent load chain per cell.
-        constexpr int NE = (AH * AW + 255) / 256;
-        constexpr int BATCH = OFLK_BATCH;
+        if (MODE == MODE_ITER) {
+            // Per-cell path (adjacent lanes = adjacent cells, so the bilinear gathers of a
+            // wave touch 2-3 cache lines per instruction).  All coalesced loads of the
+            // thread's NE cells go out first, then the gathers in batches of BATCH cells.
+            constexpr int AW = k5TX + 2 * R;                 // 70 cells per row (x0-3 ..)
+            constexpr int NE = (AH * AW + 255) / 256;        // 11 cells per thread
+            constexpr int BATCH = OFLK_BATCH;
+            float p[NE], q[NE], uu[NE], vv[NE];
 #pragma unroll
-        for (int k0 = 0; k0 < NE; k0 += BATCH) {
-            float p[BATCH], q[BATCH];
-            int lo[BATCH], li[BATCH];
-            bool live[BATCH], inner[BATCH];
-            BilinearTaps tp[BATCH];
-            float t00[BATCH], t01[BATCH], t10[BATCH], t11[BATCH];
-            float uu[BATCH], vv[BATCH];
-            int gxs[BATCH], gys[BATCH];
-#pragma unroll
-            for (int j = 0; j < BATCH; j++) {
-                int e = tid + (k0 + j) * 256;
-                live[j] = (k0 + j < NE) && e < AH * AW;
-                if (!live[j]) e = AH * AW - 1;
+            for (int k = 0; k < NE; k++) {
+                int e = min(tid + k * 256, AH * AW - 1);
                 int r = e / AW, c = e - r * AW;
                 int gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
                 int gx = min(max(x0 - R + c, 0), W - 1);
-                int i = gy * W + gx;
-                lo[j] = r * AS + c;
-                li[j] = (r - 1) * PW + (c - 1);
-                inner[j] = r >= 1 && r < AH - 1 && c >= 1 && c < AW - 1;
-                gxs[j] = gx;
-                gys[j] = gy;
-                p[j] = prev[i];
-                if (MODE == MODE_ITER) {
-                    uu[j] = fu_in[i];
-                    vv[j] = fv_in[i];
-                } else {
-                    q[j] = curr[i];
-                }
+                unsigned i = (unsigned)(gy * W + gx);
+                p[k] = prev[i];
+                uu[k] = fu_in[i];
+                vv[k] = fv_in[i];
             }
-            if (MODE == MODE_ITER) {
+#pragma unroll
+            for (int k0 = 0; k0 < NE; k0 += BATCH) {
+                BilinearTaps tp[BATCH];
+                float t00[BATCH], t01[BATCH], t10[BATCH], t11[BATCH];
 #pragma unroll
                 for (int j = 0; j < BATCH; j++) {
-                    double xs = (double)gxs[j] + (double)uu[j];  // lucas_kanade_pyramidal.py:88-89
-                    double ys = (double)gys[j] + (double)vv[j];
-                    tp[j] = bilinear_taps(H, W, ys, xs);
-                    t00[j] = curr[tp[j].i00];
-                    t01[j] = curr[tp[j].i01];
-                    t10[j] = curr[tp[j].i10];
-                    t11[j] = curr[tp[j].i11];
+                    if (k0 + j < NE) {
+                        int e = min(tid + (k0 + j) * 256, AH * AW - 1);
+                        int r = e / AW, c = e - r * AW;
+                        int gy = min(max(y0 - R + r, 0), H - 1);
+                        int gx = min(max(x0 - R + c, 0), W - 1);
+                        double xs = (double)gx + (double)uu[k0 + j];  // lucas_kanade_pyramidal.py:88-89
+                        double ys = (double)gy + (double)vv[k0 + j];
+                        tp[j] = bilinear_taps(H, W, ys, xs);
+                        t00[j] = curr[(unsigned)tp[j].i00];
+                        t01[j] = curr[(unsigned)tp[j].i01];
+                        t10[j] = curr[(unsigned)tp[j].i10];
+                        t11[j] = curr[(unsigned)tp[j].i11];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < BATCH; j++)
-                    q[j] = bilinear_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
+                    if (k0 + j < NE) q[k0 + j] = bilinear_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
             }
 #pragma unroll
-            for (int j = 0; j < BATCH; j++) {
-                if (live[j]) {
-                    float sum = p[j] + q[j];
-                    s_avg[lo[j]] = sum * 0.5f;
-                    if (inner[j]) s_it[li[j]] = p[j] - q[j];
+            for (int k = 0; k < NE; k++) {
+                int e = tid + k * 256;
+                if (e < AH * AW) {
+                    int r = e / AW, c = e - r * AW;
+                    float sum = p[k] + q[k];
+                    s_avg[r * AS + c + 1] = sum * 0.5f;   // staging column = cell column + 1
+                    s_it[r * AS + c + 1] = p[k] - q[k];
+                }
+            }
+        } else {
+            // clamped image coordinates of group g's first cell; `whole` = the group is one
+            // aligned float4 inside the image
+            auto group_pos = [&](int g, int &gy, int &gx, bool &whole) {
+                g = min(g, NGRP - 1);
+                int r = g / k5GW, c4 = g - r * k5GW;
+                gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
+                gx = x0 - 4 + 4 * c4;
+                whole = VEC && gx >= 0 && gx + 3 < W;
+            };
+            auto load4 = [&](const float *__restrict__ src, int gy, int gx, bool whole) -> float4 {
+                if (whole) return *reinterpret_cast<const float4 *>(src + (unsigned)(gy * W + gx));
+                const float *row = src + (unsigned)(gy * W);
+                float4 r;
+                r.x = row[min(max(gx, 0), W - 1)];
+                r.y = row[min(max(gx + 1, 0), W - 1)];
+                r.z = row[min(max(gx + 2, 0), W - 1)];
+                r.w = row[min(max(gx + 3, 0), W - 1)];
+                return r;
+            };
+            // every coalesced load of the thread's NV groups goes out first (one HBM latency
+            // per tile), then, in ITER mode, 16 bilinear gathers per group
+            float4 p4[NV], q4[NV], u4[NV], v4[NV];
+    #pragma unroll
+            for (int k = 0; k < NV; k++) {
+                int gy, gx;
+                bool whole;
+                group_pos(tid + k * 256, gy, gx, whole);
+                p4[k] = load4(prev, gy, gx, whole);
+                if (MODE == MODE_ITER) {
+                    u4[k] = load4(fu_in, gy, gx, whole);
+                    v4[k] = load4(fv_in, gy, gx, whole);
+                } else {
+                    q4[k] = load4(curr, gy, gx, whole);
+                }
+            }
+    #pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const int g = tid + k * 256;
+                if (MODE == MODE_ITER) {
+                    int gy, gx;
+                    bool whole;
+                    group_pos(g, gy, gx, whole);
+                    const float uu[4] = {u4[k].x, u4[k].y, u4[k].z, u4[k].w};
+                    const float vv[4] = {v4[k].x, v4[k].y, v4[k].z, v4[k].w};
+                    BilinearTaps tp[4];
+                    float t00[4], t01[4], t10[4], t11[4], qq[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        int cx = min(max(gx + j, 0), W - 1);
+                        double xs = (double)cx + (double)uu[j];  // lucas_kanade_pyramidal.py:88-89
+                        double ys = (double)gy + (double)vv[j];
+                        tp[j] = bilinear_taps(H, W, ys, xs);
+                        t00[j] = curr[(unsigned)tp[j].i00];
+                        t01[j] = curr[(unsigned)tp[j].i01];
+                        t10[j] = curr[(unsigned)tp[j].i10];
+                        t11[j] = curr[(unsigned)tp[j].i11];
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) qq[j] = bilinear_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
+                    q4[k] = make_float4(qq[0], qq[1], qq[2], qq[3]);
+                }
+                if (g < NGRP) {
+                    float4 pp = p4[k], qv = q4[k], av, dv;
+                    // (prev + curr) / 2.0 and prev - curr, lucas_kanade_core.py:36, :43
+                    av.x = (pp.x + qv.x) * 0.5f; av.y = (pp.y + qv.y) * 0.5f;
+                    av.z = (pp.z + qv.z) * 0.5f; av.w = (pp.w + qv.w) * 0.5f;
+                    dv.x = pp.x - qv.x; dv.y = pp.y - qv.y; dv.z = pp.z - qv.z; dv.w = pp.w - qv.w;
+                    *reinterpret_cast<float4 *>(&s_avg[4 * g]) = av;  // 4*g = r*AS + 4*c4
+                    *reinterpret_cast<float4 *>(&s_it[4 * g]) = dv;
                 }
             }
         }
@@ -612,7 +711,8 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             int e = tid + k * 256;
             if (e >= PH * PW) e = PH * PW - 1;  // tail threads recompute the last cell
             int r = e / PW, c = e - r * PW;
-            const float *ap = &s_avg[(r + 1) * AS + (c + 1)];
+            // gradient cell (r, c) = image (y0-2+r, x0-2+c) = staging cell (r+1, c+2)
+            const float *ap = &s_avg[(r + 1) * AS + (c + 2)];
             float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
             float a_0m = ap[-1], a_0p = ap[1];
             float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
@@ -630,7 +730,7 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             iy = fmaf(a_mm, 0.125f, iy);
             gix[k] = ix;
             giy[k] = iy;
-            git[k] = s_it[e];
+            git[k] = s_it[(r + 1) * AS + (c + 2)];
         }
         __syncthreads();  // everyone is done reading avg / It: the planes may overwrite them
     }
@@ -760,10 +860,8 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
         if (tid == 0) {
             double tu = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
             double tv = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
-            size_t nblk = (size_t)gridDim.x * gridDim.y;
-            size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-            a.partial[((size_t)b * nblk + blk) * 2 + 0] = tu;
-            a.partial[((size_t)b * nblk + blk) * 2 + 1] = tv;
+            a.partial[(size_t)tile * 2 + 0] = tu;   // tile = b * tiles_per_pair + index in pair
+            a.partial[(size_t)tile * 2 + 1] = tv;
         }
     }
 }
