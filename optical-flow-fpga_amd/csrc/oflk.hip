@@ -245,6 +245,8 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
 }
 
 inline dim3 grid2d(int W, int H, int n) { return dim3((W + 63) / 64, (H + 3) / 4, n); }
+// k_resample: 4 outputs per thread along x
+inline dim3 grid_resample(int W, int H, int n) { return dim3((W + 255) / 256, (H + 3) / 4, n); }
 
 // does every 32 x 16 coarse tile's source span fit the fused kernel's LDS tile?
 // (exactly the index arithmetic of k_pyr_down, evaluated for each tile row / column)
@@ -303,7 +305,7 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
     r.apply_scale = 0;
     {
         Prof pr(plan, s, KC_RESAMPLE);
-        hipLaunchKernelGGL(k_resample, grid2d(wo, ho, nimg), dim3(256), 0, s, r);
+        hipLaunchKernelGGL(k_resample, grid_resample(wo, ho, nimg), dim3(256), 0, s, r);
     }
     HIP_TRY(hipGetLastError());
     return OFLK_OK;
@@ -527,7 +529,7 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
             r.nplanes = 2;
             r.apply_scale = 1;
             Prof pr(p, s, KC_UPSAMPLE);
-            hipLaunchKernelGGL(k_resample, grid2d(w, h, B), dim3(256), 0, s, r);
+            hipLaunchKernelGGL(k_resample, grid_resample(w, h, B), dim3(256), 0, s, r);
             HIP_TRY(hipGetLastError());
         }
         const float *lp = (l == L - 1) ? d_prev : p->pyr[l];
@@ -902,7 +904,7 @@ OFLK_API int oflk_upsample_flow(const float *flow_u, const float *flow_v, int Hc
     r.lx = make_linspace(Wc, Wt);
     r.nplanes = 2;
     r.apply_scale = 1;
-    hipLaunchKernelGGL(k_resample, grid2d(Wt, Ht, 1), dim3(256), 0, nullptr, r);
+    hipLaunchKernelGGL(k_resample, grid_resample(Wt, Ht, 1), dim3(256), 0, nullptr, r);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(u_out, ou, nt * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipMemcpyAsync(v_out, ov, nt * sizeof(float), hipMemcpyDeviceToHost, nullptr));

@@ -979,22 +979,63 @@ struct ResampleArgs {
     int apply_scale;
 };
 
+// One thread produces 4 horizontally adjacent outputs of both planes: the row taps and
+// weights are computed once, the stores are 16 bytes per lane.  grid = (ceil(Wo/256),
+// ceil(Ho/4), nimg), block = 64 x 4.
 __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
 {
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (j >= a.Wo || i >= a.Ho) return;
+    if (j0 >= a.Wo || i >= a.Ho) return;
     const int img = blockIdx.z;
-    const size_t ip = (size_t)a.H * a.W, op = (size_t)a.Ho * a.Wo;
+    const int H = a.H, W = a.W;
+    const size_t ip = (size_t)H * W, op = (size_t)a.Ho * a.Wo;
     size_t selofs = 0;
     if (a.sel) selofs = (size_t)a.sel[img] * a.in_sel_stride;
-    double y = linspace_at(a.ly, i);
-    double x = linspace_at(a.lx, j);
-    BilinearTaps t = bilinear_taps(a.H, a.W, y, x);
-    for (int p = 0; p < a.nplanes; p++) {
-        float r = bilinear_apply(a.in[p] + selofs + (size_t)img * ip, t);
-        if (a.apply_scale) r = r * a.scale[p];
-        a.out[p][(size_t)img * op + (size_t)i * a.Wo + j] = r;
+    // row part of map_coordinates(order=1, mode="constant")
+    const double y = linspace_at(a.ly, i);
+    const bool y_in = !(y < 0.0 || y > (double)(H - 1));
+    const double fy = floor(y);
+    int y0 = min(max((int)fy, 0), H - 1);
+    const double wy0 = 1.0 - (y - fy), wy1 = 1.0 - wy0;
+    const int y1 = (y0 + 1 < H) ? y0 + 1 : (H > 1 ? H - 2 : 0);
+    float res[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = min(j0 + k, a.Wo - 1);
+        const double x = linspace_at(a.lx, j);
+        const bool inside = y_in && !(x < 0.0 || x > (double)(W - 1));
+        const double fx = floor(x);
+        int x0 = min(max((int)fx, 0), W - 1);
+        const double wx0 = 1.0 - (x - fx), wx1 = 1.0 - wx0;
+        const int x1 = (x0 + 1 < W) ? x0 + 1 : (W > 1 ? W - 2 : 0);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            if (p < a.nplanes) {
+                const float *__restrict__ src = a.in[p] + selofs + (size_t)img * ip;
+                double acc = 0.0, c;
+                c = (double)src[y0 * W + x0]; c = c * wy0; c = c * wx0; acc = acc + c;
+                c = (double)src[y0 * W + x1]; c = c * wy0; c = c * wx1; acc = acc + c;
+                c = (double)src[y1 * W + x0]; c = c * wy1; c = c * wx0; acc = acc + c;
+                c = (double)src[y1 * W + x1]; c = c * wy1; c = c * wx1; acc = acc + c;
+                float r = inside ? (float)acc : 0.0f;
+                if (a.apply_scale) r = r * a.scale[p];
+                res[p][k] = r;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        if (p < a.nplanes) {
+            float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
+            if ((a.Wo & 3) == 0) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(res[p][0], res[p][1], res[p][2], res[p][3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (j0 + k < a.Wo) dst[k] = res[p][k];
+            }
+        }
     }
 }
 
