@@ -88,6 +88,55 @@ __device__ __forceinline__ float bilinear_f64(const float *__restrict__ img, int
     return bilinear_apply(img, t);
 }
 
+// clamp(x, 0, hi) in one instruction (the compiler only forms v_med3 for constant bounds)
+__device__ __forceinline__ int clamp0(int x, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+
+// Lean form of the same sampling for the fused iteration kernel: the four tap offsets
+// are one base plus two steps, and the range test runs on the integer floors
+// (y < 0 <=> floor(y) < 0;  y > H-1 <=> floor(y) > H-1, or floor(y) == H-1 with a
+// non-zero fraction).  Same values as bilinear_taps + bilinear_finish.
+struct LeanTaps {
+    unsigned base;   // offset of tap (y0, x0); 0 when outside
+    int dx, dyw;     // steps to the x+1 / y+1 taps (mirrored at the last index, as SciPy)
+    double wy0, wy1, wx0, wx1;
+    bool inside;
+};
+
+__device__ __forceinline__ LeanTaps lean_taps(int H, int W, int gy, int gx, float u, float v)
+{
+    LeanTaps t;
+    const double y = (double)gy + (double)v;   // int64 + float32 -> float64, as the reference
+    const double x = (double)gx + (double)u;
+    const double fy = floor(y), fx = floor(x);
+    const int y0 = (int)fy, x0 = (int)fx;      // saturating; NaN -> 0
+    const double ry = y - fy, rx = x - fx;
+    t.inside = y0 >= 0 && x0 >= 0 && (y0 < H - 1 || (y0 == H - 1 && ry == 0.0)) &&
+               (x0 < W - 1 || (x0 == W - 1 && rx == 0.0));
+    t.wy0 = 1.0 - ry;
+    t.wx0 = 1.0 - rx;
+    t.wy1 = 1.0 - t.wy0;
+    t.wx1 = 1.0 - t.wx0;
+    t.base = t.inside ? (unsigned)(y0 * W + x0) : 0u;
+    t.dx = t.inside ? ((x0 + 1 < W) ? 1 : (W > 1 ? -1 : 0)) : 0;
+    t.dyw = t.inside ? ((y0 + 1 < H) ? W : (H > 1 ? -W : 0)) : 0;
+    return t;
+}
+
+__device__ __forceinline__ float lean_finish(const LeanTaps &t, float p00, float p01, float p10, float p11)
+{
+    double acc = 0.0, c;
+    c = (double)p00; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
+    c = (double)p01; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
+    c = (double)p10; c = c * t.wy1; c = c * t.wx0; acc = acc + c;
+    c = (double)p11; c = c * t.wy1; c = c * t.wx1; acc = acc + c;
+    return t.inside ? (float)acc : 0.0f;
+}
+
 // np.linspace(0, S-1, T)[i]; `step` = (double)(S-1)/(double)(T-1) from the host
 struct Linspace {
     double step;
@@ -582,53 +631,67 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             // Per-cell path (adjacent lanes = adjacent cells, so the bilinear gathers of a
             // wave touch 2-3 cache lines per instruction).  All coalesced loads of the
             // thread's NE cells go out first, then the gathers in batches of BATCH cells.
+            // Cell k of a thread is e = tid + 256 k; (row, col) advance by (3, 46) with carry
+            // at 70 columns, which avoids a division per cell.
             constexpr int AW = k5TX + 2 * R;                 // 70 cells per row (x0-3 ..)
             constexpr int NE = (AH * AW + 255) / 256;        // 11 cells per thread
             constexpr int BATCH = OFLK_BATCH;
+            static_assert(256 == 3 * AW + 46, "cell stepping assumes 70-column rows");
+            const int r0 = tid / AW, c0 = tid - r0 * AW;
+            const int Hm1 = H - 1, Wm1 = W - 1;
             float p[NE], q[NE], uu[NE], vv[NE];
+            {
+                int r = r0, c = c0;
 #pragma unroll
-            for (int k = 0; k < NE; k++) {
-                int e = min(tid + k * 256, AH * AW - 1);
-                int r = e / AW, c = e - r * AW;
-                int gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
-                int gx = min(max(x0 - R + c, 0), W - 1);
-                unsigned i = (unsigned)(gy * W + gx);
-                p[k] = prev[i];
-                uu[k] = fu_in[i];
-                vv[k] = fv_in[i];
-            }
-#pragma unroll
-            for (int k0 = 0; k0 < NE; k0 += BATCH) {
-                BilinearTaps tp[BATCH];
-                float t00[BATCH], t01[BATCH], t10[BATCH], t11[BATCH];
-#pragma unroll
-                for (int j = 0; j < BATCH; j++) {
-                    if (k0 + j < NE) {
-                        int e = min(tid + (k0 + j) * 256, AH * AW - 1);
-                        int r = e / AW, c = e - r * AW;
-                        int gy = min(max(y0 - R + r, 0), H - 1);
-                        int gx = min(max(x0 - R + c, 0), W - 1);
-                        double xs = (double)gx + (double)uu[k0 + j];  // lucas_kanade_pyramidal.py:88-89
-                        double ys = (double)gy + (double)vv[k0 + j];
-                        tp[j] = bilinear_taps(H, W, ys, xs);
-                        t00[j] = curr[(unsigned)tp[j].i00];
-                        t01[j] = curr[(unsigned)tp[j].i01];
-                        t10[j] = curr[(unsigned)tp[j].i10];
-                        t11[j] = curr[(unsigned)tp[j].i11];
-                    }
+                for (int k = 0; k < NE; k++) {
+                    int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);  // "symm" ring; farther cells are never used
+                    int gx = clamp0(x0 - R + c, Wm1);
+                    unsigned i = (unsigned)(gy * W + gx);
+                    p[k] = prev[i];
+                    uu[k] = fu_in[i];
+                    vv[k] = fv_in[i];
+                    c += 46; r += 3;
+                    if (c >= AW) { c -= AW; r += 1; }
                 }
-#pragma unroll
-                for (int j = 0; j < BATCH; j++)
-                    if (k0 + j < NE) q[k0 + j] = bilinear_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
             }
+            {
+                int r = r0, c = c0;
 #pragma unroll
-            for (int k = 0; k < NE; k++) {
-                int e = tid + k * 256;
-                if (e < AH * AW) {
-                    int r = e / AW, c = e - r * AW;
-                    float sum = p[k] + q[k];
-                    s_avg[r * AS + c + 1] = sum * 0.5f;   // staging column = cell column + 1
-                    s_it[r * AS + c + 1] = p[k] - q[k];
+                for (int k0 = 0; k0 < NE; k0 += BATCH) {
+                    LeanTaps tp[BATCH];
+                    float t00[BATCH], t01[BATCH], t10[BATCH], t11[BATCH];
+#pragma unroll
+                    for (int j = 0; j < BATCH; j++) {
+                        if (k0 + j < NE) {
+                            int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);
+                            int gx = clamp0(x0 - R + c, Wm1);
+                            tp[j] = lean_taps(H, W, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
+                            // 32-bit element offsets from the (uniform) plane pointer
+                            const unsigned b00 = tp[j].base, b10 = b00 + (unsigned)tp[j].dyw;
+                            t00[j] = curr[b00];
+                            t01[j] = curr[b00 + (unsigned)tp[j].dx];
+                            t10[j] = curr[b10];
+                            t11[j] = curr[b10 + (unsigned)tp[j].dx];
+                            c += 46; r += 3;
+                            if (c >= AW) { c -= AW; r += 1; }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < BATCH; j++)
+                        if (k0 + j < NE) q[k0 + j] = lean_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
+                }
+            }
+            {
+                int r = r0, c = c0;
+#pragma unroll
+                for (int k = 0; k < NE; k++) {
+                    if (r < AH) {
+                        float sum = p[k] + q[k];
+                        s_avg[r * AS + c + 1] = sum * 0.5f;   // staging column = cell column + 1
+                        s_it[r * AS + c + 1] = p[k] - q[k];
+                    }
+                    c += 46; r += 3;
+                    if (c >= AW) { c -= AW; r += 1; }
                 }
             }
         } else {
