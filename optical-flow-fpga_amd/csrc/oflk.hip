@@ -268,6 +268,39 @@ bool pyr_fused_fits(int h, int w, int ho, int wo, const GaussW &g)
     return span_ok(h, ho, kPTH, kPBH) && span_ok(w, wo, kPTW, kPBW);
 }
 
+// does every 256 x 4 output block of k_upsample find its coarse source span inside the
+// staged LDS tile?  (same index arithmetic as the kernel)
+bool upsample_fits(int hc, int wc, int ht, int wt)
+{
+    auto span_ok = [](int S, int T, int tile, int cap) {
+        Linspace l = make_linspace(S, T);
+        auto at = [&](int i) { return T <= 1 ? 0.0 : (i == T - 1 ? l.last : (double)i * l.step); };
+        for (int t0 = 0; t0 < T; t0 += tile) {
+            int last = std::min(t0 + tile, T) - 1;
+            int lo = (int)std::floor(at(t0));
+            if (t0 + tile >= T) lo = std::min(lo, std::max(S - 2, 0));
+            int hi = std::min((int)std::floor(at(last)) + 1, S - 1);
+            if (hi - lo + 1 > cap) return false;
+        }
+        return true;
+    };
+    return span_ok(hc, ht, kUTH, kUSH) && span_ok(wc, wt, kUTW, kUSW);
+}
+
+// upsample_flow of `nimg` flow fields (both planes); r is fully populated by the caller
+int launch_upsample(oflk_plan *plan, hipStream_t s, const ResampleArgs &r, int nimg)
+{
+    Prof pr(plan, s, KC_UPSAMPLE);
+    if (upsample_fits(r.H, r.W, r.Ho, r.Wo)) {
+        dim3 grid((r.Wo + kUTW - 1) / kUTW, (r.Ho + kUTH - 1) / kUTH, nimg);
+        hipLaunchKernelGGL(k_upsample, grid, dim3(256), 0, s, r);
+    } else {
+        hipLaunchKernelGGL(k_resample<2>, grid_resample(r.Wo, r.Ho, nimg), dim3(256), 0, s, r);
+    }
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
 // gaussian blur + linspace resample of `nimg` images: in [nimg][h][w] -> out [nimg][ho][wo]
 int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const float *in, float *out,
                     float *tmpA, float *tmpB, int nimg, int h, int w, int ho, int wo)
@@ -305,7 +338,7 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
     r.apply_scale = 0;
     {
         Prof pr(plan, s, KC_RESAMPLE);
-        hipLaunchKernelGGL(k_resample, grid_resample(wo, ho, nimg), dim3(256), 0, s, r);
+        hipLaunchKernelGGL(k_resample<1>, grid_resample(wo, ho, nimg), dim3(256), 0, s, r);
     }
     HIP_TRY(hipGetLastError());
     return OFLK_OK;
@@ -528,9 +561,8 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
             r.lx = make_linspace(wc, w);
             r.nplanes = 2;
             r.apply_scale = 1;
-            Prof pr(p, s, KC_UPSAMPLE);
-            hipLaunchKernelGGL(k_resample, grid_resample(w, h, B), dim3(256), 0, s, r);
-            HIP_TRY(hipGetLastError());
+            rc = launch_upsample(p, s, r, B);
+            if (rc) return rc;
         }
         const float *lp = (l == L - 1) ? d_prev : p->pyr[l];
         const float *lc = (l == L - 1) ? d_curr : p->pyr[l] + (size_t)B * n;
@@ -904,8 +936,7 @@ OFLK_API int oflk_upsample_flow(const float *flow_u, const float *flow_v, int Hc
     r.lx = make_linspace(Wc, Wt);
     r.nplanes = 2;
     r.apply_scale = 1;
-    hipLaunchKernelGGL(k_resample, grid_resample(Wt, Ht, 1), dim3(256), 0, nullptr, r);
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_upsample(nullptr, nullptr, r, 1))) return rc;
     HIP_TRY(hipMemcpyAsync(u_out, ou, nt * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipMemcpyAsync(v_out, ov, nt * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));

@@ -1042,9 +1042,10 @@ struct ResampleArgs {
     int apply_scale;
 };
 
-// One thread produces 4 horizontally adjacent outputs of both planes: the row taps and
-// weights are computed once, the stores are 16 bytes per lane.  grid = (ceil(Wo/256),
-// ceil(Ho/4), nimg), block = 64 x 4.
+// One thread produces 4 horizontally adjacent outputs of NP planes: the row taps and
+// weights are computed once, all 16*NP tap loads are issued before any arithmetic, and
+// the stores are 16 bytes per lane.  grid = (ceil(Wo/256), ceil(Ho/4), nimg), block = 64 x 4.
+template <int NP>
 __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
 {
     const int j0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -1059,45 +1060,62 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
     const double y = linspace_at(a.ly, i);
     const bool y_in = !(y < 0.0 || y > (double)(H - 1));
     const double fy = floor(y);
-    int y0 = min(max((int)fy, 0), H - 1);
+    const int y0 = min(max((int)fy, 0), H - 1);
     const double wy0 = 1.0 - (y - fy), wy1 = 1.0 - wy0;
     const int y1 = (y0 + 1 < H) ? y0 + 1 : (H > 1 ? H - 2 : 0);
-    float res[2][4];
+    const unsigned row0 = (unsigned)(y0 * W), row1 = (unsigned)(y1 * W);
+    double wx0[4], wx1[4];
+    bool inside[4];
+    float t[NP][4][4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = min(j0 + k, a.Wo - 1);
         const double x = linspace_at(a.lx, j);
-        const bool inside = y_in && !(x < 0.0 || x > (double)(W - 1));
+        inside[k] = y_in && !(x < 0.0 || x > (double)(W - 1));
         const double fx = floor(x);
-        int x0 = min(max((int)fx, 0), W - 1);
-        const double wx0 = 1.0 - (x - fx), wx1 = 1.0 - wx0;
+        const int x0 = min(max((int)fx, 0), W - 1);
+        wx0[k] = 1.0 - (x - fx);
+        wx1[k] = 1.0 - wx0[k];
         const int x1 = (x0 + 1 < W) ? x0 + 1 : (W > 1 ? W - 2 : 0);
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            if (p < a.nplanes) {
-                const float *__restrict__ src = a.in[p] + selofs + (size_t)img * ip;
-                double acc = 0.0, c;
-                c = (double)src[y0 * W + x0]; c = c * wy0; c = c * wx0; acc = acc + c;
-                c = (double)src[y0 * W + x1]; c = c * wy0; c = c * wx1; acc = acc + c;
-                c = (double)src[y1 * W + x0]; c = c * wy1; c = c * wx0; acc = acc + c;
-                c = (double)src[y1 * W + x1]; c = c * wy1; c = c * wx1; acc = acc + c;
-                float r = inside ? (float)acc : 0.0f;
-                if (a.apply_scale) r = r * a.scale[p];
-                res[p][k] = r;
-            }
+        for (int p = 0; p < NP; p++) {
+            const float *__restrict__ src = a.in[p] + selofs + (size_t)img * ip;
+#if defined(OFLK_RES_ABLATE) && OFLK_RES_ABLATE == 1
+            t[p][k][0] = (float)x0; t[p][k][1] = (float)x1; t[p][k][2] = (float)y0; t[p][k][3] = (float)(x0 + y1);
+            (void)src;
+#else
+            t[p][k][0] = src[row0 + (unsigned)x0];
+            t[p][k][1] = src[row0 + (unsigned)x1];
+            t[p][k][2] = src[row1 + (unsigned)x0];
+            t[p][k][3] = src[row1 + (unsigned)x1];
+#endif
         }
     }
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-        if (p < a.nplanes) {
-            float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
-            if ((a.Wo & 3) == 0) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(res[p][0], res[p][1], res[p][2], res[p][3]);
-            } else {
+    for (int p = 0; p < NP; p++) {
+        float res[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (j0 + k < a.Wo) dst[k] = res[p][k];
-            }
+        for (int k = 0; k < 4; k++) {
+            double acc = 0.0, c;
+            c = (double)t[p][k][0]; c = c * wy0; c = c * wx0[k]; acc = acc + c;
+            c = (double)t[p][k][1]; c = c * wy0; c = c * wx1[k]; acc = acc + c;
+            c = (double)t[p][k][2]; c = c * wy1; c = c * wx0[k]; acc = acc + c;
+            c = (double)t[p][k][3]; c = c * wy1; c = c * wx1[k]; acc = acc + c;
+            float r = inside[k] ? (float)acc : 0.0f;
+            if (a.apply_scale) r = r * a.scale[p];
+            res[k] = r;
+        }
+        float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
+#if defined(OFLK_RES_ABLATE) && OFLK_RES_ABLATE == 2
+        if (res[0] == 123456.789f) {
+#else
+        if ((a.Wo & 3) == 0) {
+#endif
+            *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (j0 + k < a.Wo) dst[k] = res[k];
         }
     }
 }
@@ -1152,12 +1170,24 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
     if (i0 + kPTH >= a.Ho) ylo = min(ylo, max(H - 2, 0));
     if (j0 + kPTW >= a.Wo) xlo = min(xlo, max(W - 2, 0));
 
-    // ---- A: input tile, reflect-extended ------------------------------------
-    for (int e = tid; e < kPIH * kPIW; e += 256) {
-        int r = e / kPIW, c = e - r * kPIW;
-        int gy = reflect_idx(ylo - 8 + r, H);
-        int gx = reflect_idx(xlo - 8 + c, W);
-        s_in[e] = src[(size_t)gy * W + gx];
+    // ---- A: input tile, reflect-extended; all of a thread's loads go out before the
+    // first LDS write (one memory latency per tile instead of one per element) ---------
+    {
+        constexpr int NA = (kPIH * kPIW + 255) / 256;  // 17 elements per thread
+        float vals[NA];
+#pragma unroll
+        for (int k = 0; k < NA; k++) {
+            int e = min(tid + k * 256, kPIH * kPIW - 1);
+            int r = e / kPIW, c = e - r * kPIW;
+            int gy = reflect_idx(ylo - 8 + r, H);
+            int gx = reflect_idx(xlo - 8 + c, W);
+            vals[k] = src[(unsigned)(gy * W + gx)];
+        }
+#pragma unroll
+        for (int k = 0; k < NA; k++) {
+            int e = tid + k * 256;
+            if (e < kPIH * kPIW) s_in[e] = vals[k];
+        }
     }
     __syncthreads();
 
@@ -1237,6 +1267,99 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
             r = (float)acc;
         }
         dst[(size_t)i * a.Wo + j] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4: upsample_flow (lucas_kanade_pyramidal.py:100-138) with the coarse tile staged in
+// LDS.  A block produces 256 x 4 fine outputs of both planes; the coarse cells it
+// samples (at most kUSW columns x kUSH rows per plane) are fetched with coalesced
+// loads once, and the 16 taps per plane of each thread come from LDS (gathering them
+// from global memory made the kernel L1-throughput bound).  Same arithmetic as
+// k_resample<2> with scaling; the host checks that every block's source span fits
+// (upsample_fits) and falls back to k_resample<2> otherwise.
+// ---------------------------------------------------------------------------
+constexpr int kUTW = 256, kUTH = 4;   // fine outputs per block
+constexpr int kUSW = 136, kUSH = 4;   // coarse columns / rows staged per plane
+
+__global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
+{
+    __shared__ float s_src[2][kUSH][kUSW];
+    const int tid = threadIdx.x;
+    const int jb = blockIdx.x * kUTW, ib = blockIdx.y * kUTH;
+    const int img = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const size_t ip = (size_t)H * W, op = (size_t)a.Ho * a.Wo;
+    size_t selofs = 0;
+    if (a.sel) selofs = (size_t)a.sel[img] * a.in_sel_stride;
+    // first coarse row / column any tap of this block touches (a sample that lands
+    // exactly on the last index reads the mirrored index N-2 with weight 0)
+    int ylo = (int)floor(linspace_at(a.ly, ib));
+    int xlo = (int)floor(linspace_at(a.lx, jb));
+    if (ib + kUTH >= a.Ho) ylo = min(ylo, max(H - 2, 0));
+    if (jb + kUTW >= a.Wo) xlo = min(xlo, max(W - 2, 0));
+    {
+        constexpr int NL = (2 * kUSH * kUSW + 255) / 256;  // 5 staged cells per thread
+        float vals[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int e = min(tid + k * 256, 2 * kUSH * kUSW - 1);
+            int p = e / (kUSH * kUSW);
+            int rem = e - p * (kUSH * kUSW);
+            int r = rem / kUSW, c = rem - r * kUSW;
+            int gy = min(ylo + r, H - 1), gx = min(xlo + c, W - 1);
+            vals[k] = (a.in[p] + selofs + (size_t)img * ip)[(unsigned)(gy * W + gx)];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int e = tid + k * 256;
+            if (e < 2 * kUSH * kUSW) (&s_src[0][0][0])[e] = vals[k];
+        }
+    }
+    __syncthreads();
+
+    const int j0 = jb + (tid & 63) * 4;
+    const int i = ib + (tid >> 6);
+    if (j0 >= a.Wo || i >= a.Ho) return;
+    const double y = linspace_at(a.ly, i);
+    const bool y_in = !(y < 0.0 || y > (double)(H - 1));
+    const double fy = floor(y);
+    const int y0 = min(max((int)fy, 0), H - 1);
+    const double wy0 = 1.0 - (y - fy), wy1 = 1.0 - wy0;
+    const int y1 = (y0 + 1 < H) ? y0 + 1 : (H > 1 ? H - 2 : 0);
+    float res[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = min(j0 + k, a.Wo - 1);
+        const double x = linspace_at(a.lx, j);
+        const bool inside = y_in && !(x < 0.0 || x > (double)(W - 1));
+        const double fx = floor(x);
+        const int x0 = min(max((int)fx, 0), W - 1);
+        const double wx0 = 1.0 - (x - fx), wx1 = 1.0 - wx0;
+        const int x1 = (x0 + 1 < W) ? x0 + 1 : (W > 1 ? W - 2 : 0);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const float *r0 = &s_src[p][y0 - ylo][0] - xlo;
+            const float *r1 = &s_src[p][y1 - ylo][0] - xlo;
+            double acc = 0.0, c;
+            c = (double)r0[x0]; c = c * wy0; c = c * wx0; acc = acc + c;
+            c = (double)r0[x1]; c = c * wy0; c = c * wx1; acc = acc + c;
+            c = (double)r1[x0]; c = c * wy1; c = c * wx0; acc = acc + c;
+            c = (double)r1[x1]; c = c * wy1; c = c * wx1; acc = acc + c;
+            float r = inside ? (float)acc : 0.0f;
+            res[p][k] = r * a.scale[p];   // fp32 multiply by float32(scale), :135-136
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
+        if ((a.Wo & 3) == 0) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(res[p][0], res[p][1], res[p][2], res[p][3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (j0 + k < a.Wo) dst[k] = res[p][k];
+        }
     }
 }
 
