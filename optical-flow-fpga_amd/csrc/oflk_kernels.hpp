@@ -464,10 +464,10 @@ __global__ __launch_bounds__(kLkThreads) void k_lk(LkArgs a)
 // registers across the barrier).
 // ---------------------------------------------------------------------------
 #ifndef OFLK_NY
-#define OFLK_NY 4
+#define OFLK_NY 3
 #endif
 #ifndef OFLK_BATCH
-#define OFLK_BATCH 4
+#define OFLK_BATCH 6
 #endif
 // XCD-aware tile order (speed only, never correctness).  Workgroups of a 1-D grid are
 // dealt round-robin over the 8 XCDs (ids i and i+8 share an XCD, each with its own L2).

@@ -224,3 +224,69 @@ def test_errors_are_loud():
         K_.lucas_kanade_single_scale(a, np.zeros((8, 9), np.float32))
     with pytest.raises(_oflk.OflkError):
         K_.lucas_kanade_single_scale(a, a, 9)  # window not built -> explicit error, no fallback
+
+
+# ---- BASELINE.json full sizes ---------------------------------------------------
+@pytest.mark.parametrize("shape", [(1080, 1920), (2160, 3840)])
+def test_full_size_pyramidal_matches_oracle(P, oracle, shape):
+    """configs[2] (1080p) and one pair of configs[3] (4K): the whole call against the oracle"""
+    from oflk_synth import synth_pair
+
+    a, b = synth_pair(*shape, pair_index=1)
+    oracle.set_threads(8)
+    try:
+        _check_pyramidal(P, oracle, a, b, 3, 5, 3)
+    finally:
+        oracle.set_threads(1)
+
+
+def test_640x480_single_scale_matches_oracle(K, oracle):
+    """configs[1]"""
+    from oflk_synth import synth_pair
+
+    a, b = synth_pair(480, 640, pair_index=2)
+    u, v = K.lucas_kanade_single_scale(a, b, 5)
+    ou, ov = oracle.lucas_kanade_single_scale(a, b, 5)
+    _eq(u, ou, "u")
+    _eq(v, ov, "v")
+
+
+def test_single_scale_is_local_at_4k(K, oracle):
+    """size-independent property: single-scale flow at a pixel depends only on its 7x7
+    neighbourhood, so a crop computed alone agrees with the full-frame result on the
+    crop's interior (3-pixel rim excluded), bit for bit"""
+    from oflk_synth import synth_pair
+
+    a, b = synth_pair(2160, 3840, pair_index=3)
+    u, v = K.lucas_kanade_single_scale(a, b, 5)
+    rng = np.random.default_rng(9)
+    for _ in range(4):
+        y = int(rng.integers(0, 2160 - 200))
+        x = int(rng.integers(0, 3840 - 300))
+        cu, cv = oracle.lucas_kanade_single_scale(a[y:y + 200, x:x + 300], b[y:y + 200, x:x + 300], 5)
+        _eq(np.ascontiguousarray(u[y + 3:y + 197, x + 3:x + 297]), np.ascontiguousarray(cu[3:-3, 3:-3]), "u crop")
+        _eq(np.ascontiguousarray(v[y + 3:y + 197, x + 3:x + 297]), np.ascontiguousarray(cv[3:-3, 3:-3]), "v crop")
+
+
+def test_7x7_window_at_8k_single_scale(K, oracle):
+    """configs[4] geometry (7680x4320, 7x7 window), fp32 exact path, checked on crops"""
+    from oflk_synth import synth_pair
+
+    a, b = synth_pair(4320, 7680, pair_index=4)
+    u, v = K.lucas_kanade_single_scale(a, b, 7)
+    for (y, x) in ((0, 0), (2000, 3000), (4320 - 160, 7680 - 240)):
+        cu, cv = oracle.lucas_kanade_single_scale(a[y:y + 160, x:x + 240], b[y:y + 160, x:x + 240], 7)
+        ys = slice(0 if y == 0 else 4, 160 if y + 160 == 4320 else 156)
+        xs = slice(0 if x == 0 else 4, 240 if x + 240 == 7680 else 236)
+        _eq(np.ascontiguousarray(u[y:y + 160, x:x + 240][ys, xs]), np.ascontiguousarray(cu[ys, xs]), "u crop")
+        _eq(np.ascontiguousarray(v[y:y + 160, x:x + 240][ys, xs]), np.ascontiguousarray(cv[ys, xs]), "v crop")
+
+
+def test_repeat_calls_are_deterministic(P):
+    from oflk_synth import synth_pair
+
+    a, b = synth_pair(270, 480, pair_index=5)
+    r1 = P.lucas_kanade_pyramidal_with_log(a, b, 3, 5, 3)
+    r2 = P.lucas_kanade_pyramidal_with_log(a, b, 3, 5, 3)
+    for x, y in zip(r1, r2):
+        assert np.array_equal(x, y)
