@@ -101,11 +101,15 @@ __device__ __forceinline__ int clamp0(int x, int hi)
 // (y < 0 <=> floor(y) < 0;  y > H-1 <=> floor(y) > H-1, or floor(y) == H-1 with a
 // non-zero fraction).  Same values as bilinear_taps + bilinear_finish.
 struct LeanTaps {
-    unsigned base;   // offset of tap (y0, x0); 0 when outside
-    int dx, dyw;     // steps to the x+1 / y+1 taps (mirrored at the last index, as SciPy)
+    unsigned row0, row1;  // offsets of the two 2-pixel tap pairs (x pair starts at xb = min(x0, W-2))
+    bool swap;            // x0 == W-1: the pair is (x0-1, x0); tap x0 is its second element
     double wy0, wy1, wx0, wx1;
     bool inside;
 };
+
+// 8-byte load from a 4-byte aligned address (x0 is arbitrary); gfx950 global memory
+// accepts the unaligned dwordx2
+struct __attribute__((packed, aligned(4))) PairF { float a, b; };
 
 __device__ __forceinline__ LeanTaps lean_taps(int H, int W, int gy, int gx, float u, float v)
 {
@@ -121,14 +125,23 @@ __device__ __forceinline__ LeanTaps lean_taps(int H, int W, int gy, int gx, floa
     t.wx0 = 1.0 - rx;
     t.wy1 = 1.0 - t.wy0;
     t.wx1 = 1.0 - t.wx0;
-    t.base = t.inside ? (unsigned)(y0 * W + x0) : 0u;
-    t.dx = t.inside ? ((x0 + 1 < W) ? 1 : (W > 1 ? -1 : 0)) : 0;
-    t.dyw = t.inside ? ((y0 + 1 < H) ? W : (H > 1 ? -W : 0)) : 0;
+    // SciPy reads the mirrored neighbour (index N-2) with weight exactly 0 when a sample
+    // lands on the last index; any finite value gives the same result, so the x pair is
+    // simply shifted left by one there and the y pair re-reads row H-2
+    const bool lastx = x0 >= W - 1;
+    const int xb = t.inside ? (lastx ? max(W - 2, 0) : x0) : 0;
+    const int y0c = t.inside ? y0 : 0;
+    const int y1c = t.inside ? ((y0 + 1 < H) ? y0 + 1 : max(H - 2, 0)) : 0;
+    t.swap = t.inside && lastx && W > 1;
+    t.row0 = (unsigned)(y0c * W + xb);
+    t.row1 = (unsigned)(y1c * W + xb);
     return t;
 }
 
-__device__ __forceinline__ float lean_finish(const LeanTaps &t, float p00, float p01, float p10, float p11)
+__device__ __forceinline__ float lean_finish(const LeanTaps &t, PairF r0, PairF r1)
 {
+    const float p00 = t.swap ? r0.b : r0.a, p01 = t.swap ? r0.a : r0.b;
+    const float p10 = t.swap ? r1.b : r1.a, p11 = t.swap ? r1.a : r1.b;
     double acc = 0.0, c;
     c = (double)p00; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
     c = (double)p01; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
@@ -659,26 +672,23 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
 #pragma unroll
                 for (int k0 = 0; k0 < NE; k0 += BATCH) {
                     LeanTaps tp[BATCH];
-                    float t00[BATCH], t01[BATCH], t10[BATCH], t11[BATCH];
+                    PairF pr0[BATCH], pr1[BATCH];
 #pragma unroll
                     for (int j = 0; j < BATCH; j++) {
                         if (k0 + j < NE) {
                             int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);
                             int gx = clamp0(x0 - R + c, Wm1);
                             tp[j] = lean_taps(H, W, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
-                            // 32-bit element offsets from the (uniform) plane pointer
-                            const unsigned b00 = tp[j].base, b10 = b00 + (unsigned)tp[j].dyw;
-                            t00[j] = curr[b00];
-                            t01[j] = curr[b00 + (unsigned)tp[j].dx];
-                            t10[j] = curr[b10];
-                            t11[j] = curr[b10 + (unsigned)tp[j].dx];
+                            // two 8-byte gathers per cell (the x pair of each tap row)
+                            pr0[j] = *reinterpret_cast<const PairF *>(curr + tp[j].row0);
+                            pr1[j] = *reinterpret_cast<const PairF *>(curr + tp[j].row1);
                             c += 46; r += 3;
                             if (c >= AW) { c -= AW; r += 1; }
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < BATCH; j++)
-                        if (k0 + j < NE) q[k0 + j] = lean_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
+                        if (k0 + j < NE) q[k0 + j] = lean_finish(tp[j], pr0[j], pr1[j]);
                 }
             }
             {
@@ -1375,9 +1385,12 @@ __global__ __launch_bounds__(256) void k_warp(const float *__restrict__ img,
     const size_t plane = (size_t)H * (size_t)W;
     const size_t base = (size_t)blockIdx.z * plane;
     size_t i = (size_t)y * W + x;
-    double xs = (double)x + (double)fu[base + i];
-    double ys = (double)y + (double)fv[base + i];
-    out[base + i] = bilinear_f64(img + base, H, W, ys, xs);
+    // same tap code as the fused iteration kernel (k_lk5), so the unit tests of
+    // warp_image exercise it
+    LeanTaps t = lean_taps(H, W, y, x, fu[base + i], fv[base + i]);
+    PairF r0 = *reinterpret_cast<const PairF *>(img + base + t.row0);
+    PairF r1 = *reinterpret_cast<const PairF *>(img + base + t.row1);
+    out[base + i] = lean_finish(t, r0, r1);
 }
 
 // a1 standalone: compute_gradients (lucas_kanade_core.py:15-45)
