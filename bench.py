@@ -136,10 +136,20 @@ def main() -> None:
         avg_ms = dom["total_ms"] / dom["launches"]
         bytes_per_launch = model["finest_iteration_launch"] * B
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_lk<2,ITER> (finest level)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
-                    "algorithmic_bytes_per_launch": bytes_per_launch}
+        # HBM bytes per launch from PMC counters are collected by tools/measure_traffic.sh in
+        # separate rocprofv3 passes (they cannot be read live); used when they match this workload
+        traffic = None
+        for f in sorted((ROOT / "profiles").glob("*_hbm_traffic.json")):
+            try:
+                tr = json.loads(f.read_text())
+                if tr.get("pairs") == B and tr.get("shape") == [H, W]:
+                    traffic = tr["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+        roofline = {"bound": "hbm", "kernel": "k_lk5<ITER> (fused LK iteration, finest level)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": bytes_per_launch}
     # whole-call view: algorithmic bytes of the full pyramidal call over step time
     step_bytes = sum(algorithmic_bytes_per_pair(dims, L, runs[b])["total"] for b in range(B))
     whole = {"algorithmic_bytes_per_step": step_bytes,
