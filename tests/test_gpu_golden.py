@@ -99,3 +99,16 @@ def test_rtl_frame_pairs_on_gpu(golden_dir):
         us, vs = K.lucas_kanade_single_scale(p, c, 5)
         up, vp = P.lucas_kanade_pyramidal(p, c, 3, 5, 3)
         assert [digest(us), digest(vs), digest(up), digest(vp)] == list(r[f"{tag}__sha"])
+
+
+@pytest.mark.parametrize("name", ["translate_medium", "rotate_small", "translate_extreme", "no_motion"])
+@pytest.mark.parametrize("preset", ["shallow", "deep", "large_window"])
+def test_hip_other_presets_equal_reference(suite, golden_dir, name, preset):
+    """2-level, 4-level and 7x7 presets: HIP digests == the reference's digests"""
+    import lucas_kanade_pyramidal as P
+
+    z, _ = suite
+    ref = json.loads((golden_dir / "reference_presets.json").read_text())[name][preset]
+    p, c = z["frame_0"].astype(np.float32), z[f"frame_1__{name}"].astype(np.float32)
+    u, v = P.lucas_kanade_pyramidal(p, c, ref["levels"], ref["window_size"], ref["iterations"])
+    assert digest(u) == ref["u_sha256"] and digest(v) == ref["v_sha256"]

@@ -168,3 +168,17 @@ def test_oracle_against_scipy_and_numpy_directly(oracle):
     assert np.array_equal(oracle.resample_linspace(a, (16, 23)), ndi.map_coordinates(a, [yy, xx], order=1, mode="constant"))
     x = rng.normal(0, 1, 100000).astype(np.float32)
     assert oracle.np_sum_f32(x) == np.sum(x) and oracle.mean_abs(x) == np.mean(np.abs(x))
+
+
+PRESET_PATTERNS = ["translate_medium", "rotate_small", "translate_extreme", "no_motion"]
+
+
+@pytest.mark.parametrize("name", PRESET_PATTERNS)
+@pytest.mark.parametrize("preset", ["shallow", "deep", "large_window"])
+def test_oracle_other_presets_equal_reference(oracle, suite, golden_dir, name, preset):
+    """2-level, 4-level and 7x7 presets of verification_config.yaml (reference :78-103)"""
+    z, _ = suite
+    ref = json.loads((golden_dir / "reference_presets.json").read_text())[name][preset]
+    p, c = _pair(z, name)
+    u, v = oracle.lucas_kanade_pyramidal(p, c, ref["levels"], ref["window_size"], ref["iterations"])
+    assert digest(u) == ref["u_sha256"] and digest(v) == ref["v_sha256"]
