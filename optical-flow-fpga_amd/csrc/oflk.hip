@@ -225,21 +225,22 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
 {
     LkArgs a = a_in;
     a.B = B;
-    dim3 grid((a.W + kTX - 1) / kTX, (a.H + kTY - 1) / kTY, B);
-    dim3 block(kLkThreads);
     Prof pr(plan, s, cls);
+    // 1-D grid: the kernel decodes (pair, tile) in an XCD-aware order
+    dim3 grid((unsigned)(((a.W + k5TX - 1) / k5TX) * ((a.H + k5TY - 1) / k5TY) * B));
+    const bool vec = (a.W & 3) == 0;
+#define OFLK_LAUNCH_LKW(HWV)                                                          \
+    do {                                                                              \
+        if (vec) hipLaunchKernelGGL((k_lkw<HWV, MODE, true>), grid, dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((k_lkw<HWV, MODE, false>), grid, dim3(256), 0, s, a);     \
+    } while (0)
     switch (hw) {
-        case 1: hipLaunchKernelGGL((k_lk<1, MODE>), grid, block, 0, s, a); break;
-        case 2:
-            grid = dim3((unsigned)(((a.W + k5TX - 1) / k5TX) * ((a.H + k5TY - 1) / k5TY) * B));
-            if ((a.W & 3) == 0)
-                hipLaunchKernelGGL((k_lk5<MODE, true>), grid, dim3(256), 0, s, a);
-            else
-                hipLaunchKernelGGL((k_lk5<MODE, false>), grid, dim3(256), 0, s, a);
-            break;
-        case 3: hipLaunchKernelGGL((k_lk<3, MODE>), grid, block, 0, s, a); break;
+        case 1: OFLK_LAUNCH_LKW(1); break;
+        case 2: OFLK_LAUNCH_LKW(2); break;
+        case 3: OFLK_LAUNCH_LKW(3); break;
         default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
     }
+#undef OFLK_LAUNCH_LKW
     HIP_TRY(hipGetLastError());
     return OFLK_OK;
 }
@@ -451,7 +452,7 @@ OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, 
         // finest level: one of the ping-pong buffers is the caller's output
         int nb = (l == levels - 1) ? 1 : 2;
         if (!rc) rc = dmalloc(&p->flow[l], (size_t)nb * 2 * B * n, &p->ws_bytes);
-        size_t nblk = (size_t)((dims[2 * l + 1] + kTX - 1) / kTX) * ((dims[2 * l] + kTY - 1) / kTY);
+        size_t nblk = (size_t)((dims[2 * l + 1] + k5TX - 1) / k5TX) * ((dims[2 * l] + k5TY - 1) / k5TY);
         nblk_max = std::max(nblk_max, nblk);
     }
     if (!rc) rc = dmalloc(&p->partial, (size_t)B * nblk_max * 2, &p->ws_bytes);
@@ -566,8 +567,7 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
         }
         const float *lp = (l == L - 1) ? d_prev : p->pyr[l];
         const float *lc = (l == L - 1) ? d_curr : p->pyr[l] + (size_t)B * n;
-        const int nblk = p->hw == 2 ? ((w + k5TX - 1) / k5TX) * ((h + k5TY - 1) / k5TY)
-                                    : ((w + kTX - 1) / kTX) * ((h + kTY - 1) / kTY);
+        const int nblk = ((w + k5TX - 1) / k5TX) * ((h + k5TY - 1) / k5TY);
         for (int k = 0; k < K; k++) {
             LkArgs a{};
             a.prev = lp; a.curr = lc;

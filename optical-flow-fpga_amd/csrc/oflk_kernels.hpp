@@ -164,33 +164,6 @@ __device__ __forceinline__ double linspace_at(const Linspace &l, int i)
     return (double)i * l.step;  // step == 0 (S == 1) also yields 0, as NumPy does
 }
 
-// ---------------------------------------------------------------------------
-// NumPy pairwise sum of a (2HW+1)^2 window, n <= 128: 8 strided accumulators,
-// fixed tree, sequential tail (lucas_kanade_core.py:115-119 via np.sum).  The
-// window of output O (0..3 along x) lives in v[row][O + col].
-// ---------------------------------------------------------------------------
-template <int HW, int O>
-__device__ __forceinline__ float np_window_sum(const float (&v)[2 * HW + 1][4 + 2 * HW])
-{
-    constexpr int S = 2 * HW + 1;
-    constexpr int N = S * S;
-    static_assert(N >= 8 && N <= 128, "window must fit NumPy's unrolled pairwise block");
-    constexpr int NB = N - (N % 8);
-    float r[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = v[j / S][O + j % S];
-#pragma unroll
-    for (int i = 8; i < NB; i += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) r[j] = r[j] + v[(i + j) / S][O + (i + j) % S];
-    }
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-#pragma unroll
-    for (int i = NB; i < N; i++) res = res + v[i / S][O + i % S];
-    // the add-reduction starts from the identity: 0 + res (only turns -0 into +0)
-    return 0.0f + res;
-}
-
 // 2x2 Cramer solve, every op individually rounded (lucas_kanade_core.py:122-133)
 __device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float Sxt, float Syt,
                                          float &u, float &v)
@@ -217,16 +190,12 @@ __device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float 
 //                 warp(curr, flow) -> LK(prev, warped) -> flow_out = flow_in + d,
 //                 per-block sums of |du|, |dv|
 //   MODE_GRADS  : lucas_kanade_from_gradients(Ix, Iy, It)           -> u, v
-// One 256-thread block produces a 64 x 16 output tile; each thread 1 x 4 outputs.
-// LDS: frame-average tile with halo HW+1, It tile and five product planes with
-// halo HW.  HBM traffic per output pixel: 8 B in + 8 B out (SINGLE), 16 B in +
-// 8 B out (ITER; the warp's gathers of `curr` hit L1/L2).
+// One 256-thread block produces a 64 x 24 output tile (k_lkw below).  HBM traffic per
+// output pixel: 8 B in + 8 B out (SINGLE), 16 B in + 8 B out (ITER; the warp's
+// gathers of `curr` hit L1/L2).
 // ---------------------------------------------------------------------------
 enum { MODE_SINGLE = 0, MODE_ITER = 1, MODE_GRADS = 2 };
 
-constexpr int kTX = 64;
-constexpr int kTY = 16;
-constexpr int kLkThreads = 256;
 
 struct LkArgs {
     const float *prev;  // [B][H][W]   (MODE_GRADS: Ix)
@@ -241,223 +210,9 @@ struct LkArgs {
     int B;              // frame pairs in the launch (k_lk5 decodes pair/tile from a 1-D grid)
 };
 
-template <int HW, int MODE>
-__global__ __launch_bounds__(kLkThreads) void k_lk(LkArgs a)
-{
-    constexpr int R = HW + 1;             // halo of the frame-average tile
-    constexpr int AH = kTY + 2 * R;
-    constexpr int AW = kTX + 2 * R;
-    constexpr int AS = AW + 1;            // +1: odd stride for the column-ish Sobel reads
-    constexpr int PH = kTY + 2 * HW;      // gradient / product tile
-    constexpr int PW = kTX + 2 * HW;
-    constexpr int PS = (PW + 3) & ~3;     // rows stay 16-byte aligned for ds_read_b128
-    constexpr int S = 2 * HW + 1;
-    constexpr int NV = 4 + 2 * HW;        // product columns one thread needs per row
-
-    __shared__ float s_avg[MODE == MODE_GRADS ? 1 : AH * AS];
-    __shared__ float s_it[MODE == MODE_GRADS ? 1 : PH * PS];
-    __shared__ __attribute__((aligned(16))) float s_p[5][PH * PS];
-
-    const int b = blockIdx.z;
-    int sel = 0;
-    if (MODE == MODE_ITER) {
-        if (a.done[b]) return;  // block-uniform: level converged for this pair
-        sel = a.sel[b];
-    }
-    const int H = a.H, W = a.W;
-    const size_t plane = (size_t)H * (size_t)W;
-    const float *__restrict__ prev = a.prev + (size_t)b * plane;
-    const float *__restrict__ curr = a.curr + (size_t)b * plane;
-    const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
-    const int tid = threadIdx.x;
-
-    if (MODE == MODE_GRADS) {
-        // products straight from the caller's gradients
-        const float *__restrict__ gxp = prev;
-        const float *__restrict__ gyp = curr;
-        const float *__restrict__ gtp = a.aux + (size_t)b * plane;
-        for (int e = tid; e < PH * PW; e += kLkThreads) {
-            int r = e / PW, c = e - r * PW;
-            int gy = y0 - HW + r, gx = x0 - HW + c;
-            float ix = 0.0f, iy = 0.0f, it = 0.0f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                size_t i = (size_t)gy * W + gx;
-                ix = gxp[i];
-                iy = gyp[i];
-                it = gtp[i];
-            }
-            int o = r * PS + c;
-            s_p[0][o] = ix * ix;
-            s_p[1][o] = iy * iy;
-            s_p[2][o] = ix * iy;
-            s_p[3][o] = ix * it;
-            s_p[4][o] = iy * it;
-        }
-    } else {
-        // ---- stage 1: second frame (warped if ITER), frame average, It -------
-        const float *__restrict__ fu_in = nullptr;
-        const float *__restrict__ fv_in = nullptr;
-        if (MODE == MODE_ITER) {
-            fu_in = a.fu[sel] + (size_t)b * plane;
-            fv_in = a.fv[sel] + (size_t)b * plane;
-        }
-        for (int e = tid; e < AH * AW; e += kLkThreads) {
-            int r = e / AW, c = e - r * AW;
-            // convolve2d boundary="symm": one ring of edge repetition; farther-out
-            // halo cells only feed windows that are never evaluated
-            int gy = min(max(y0 - R + r, 0), H - 1);
-            int gx = min(max(x0 - R + c, 0), W - 1);
-            size_t i = (size_t)gy * W + gx;
-            float p = prev[i];
-            float q;
-            if (MODE == MODE_ITER) {
-                // warp_image (lucas_kanade_pyramidal.py:88-95)
-                double xs = (double)gx + (double)fu_in[i];
-                double ys = (double)gy + (double)fv_in[i];
-                q = bilinear_f64(curr, H, W, ys, xs);
-            } else {
-                q = curr[i];
-            }
-            float sum = p + q;
-            s_avg[r * AS + c] = sum * 0.5f;  // (prev + curr) / 2.0, lucas_kanade_core.py:36
-            if (r >= 1 && r < AH - 1 && c >= 1 && c < AW - 1)
-                s_it[(r - 1) * PS + (c - 1)] = p - q;  // lucas_kanade_core.py:43
-        }
-        __syncthreads();
-        // ---- stage 2: Sobel/8 as convolve2d evaluates it, then the 5 products -
-        for (int e = tid; e < PH * PW; e += kLkThreads) {
-            int r = e / PW, c = e - r * PW;
-            const float *ap = &s_avg[(r + 1) * AS + (c + 1)];
-            float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
-            float a_0m = ap[-1], a_0p = ap[1];
-            float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
-            // kernel taps in row-major order of the flipped kernel; products by
-            // powers of two are exact, so fma(a, w, s) == fl(s + fl(a*w))
-            float ix = a_pp * -0.125f;
-            ix = fmaf(a_pm, 0.125f, ix);
-            ix = fmaf(a_0p, -0.25f, ix);
-            ix = fmaf(a_0m, 0.25f, ix);
-            ix = fmaf(a_mp, -0.125f, ix);
-            ix = fmaf(a_mm, 0.125f, ix);
-            float iy = a_pp * -0.125f;
-            iy = fmaf(a_p0, -0.25f, iy);
-            iy = fmaf(a_pm, -0.125f, iy);
-            iy = fmaf(a_mp, 0.125f, iy);
-            iy = fmaf(a_m0, 0.25f, iy);
-            iy = fmaf(a_mm, 0.125f, iy);
-            int o = r * PS + c;
-            float it = s_it[o];
-            s_p[0][o] = ix * ix;
-            s_p[1][o] = iy * iy;
-            s_p[2][o] = ix * iy;
-            s_p[3][o] = ix * it;
-            s_p[4][o] = iy * it;
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 3: window sums in NumPy order, solve, write -------------------
-    const int tx = tid & 15, ty = tid >> 4;
-    float sums[5][4];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        float v[S][NV];
-#pragma unroll
-        for (int i = 0; i < S; i++) {
-            const float *row = &s_p[k][(ty + i) * PS + 4 * tx];
-#pragma unroll
-            for (int j = 0; j + 4 <= NV; j += 4) {
-                float4 q = *reinterpret_cast<const float4 *>(row + j);
-                v[i][j] = q.x; v[i][j + 1] = q.y; v[i][j + 2] = q.z; v[i][j + 3] = q.w;
-            }
-            if (NV % 4 == 2) {
-                float2 q = *reinterpret_cast<const float2 *>(row + (NV - 2));
-                v[i][NV - 2] = q.x; v[i][NV - 1] = q.y;
-            }
-        }
-        sums[k][0] = np_window_sum<HW, 0>(v);
-        sums[k][1] = np_window_sum<HW, 1>(v);
-        sums[k][2] = np_window_sum<HW, 2>(v);
-        sums[k][3] = np_window_sum<HW, 3>(v);
-    }
-
-    const int gy = y0 + ty;
-    const int gxb = x0 + 4 * tx;
-    float du[4], dv[4];
-    double su = 0.0, sv = 0.0;
-#pragma unroll
-    for (int o = 0; o < 4; o++) {
-        float u, v;
-        lk_solve(sums[0][o], sums[1][o], sums[2][o], sums[3][o], sums[4][o], u, v);
-        int gx = gxb + o;
-        // borders stay zero (lucas_kanade_core.py:101-108)
-        bool interior = gy >= HW && gy < H - HW && gx >= HW && gx < W - HW;
-        du[o] = interior ? u : 0.0f;
-        dv[o] = interior ? v : 0.0f;
-        if (MODE == MODE_ITER && gy < H && gx < W) {
-            su += (double)fabsf(du[o]);
-            sv += (double)fabsf(dv[o]);
-        }
-    }
-
-    float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
-    float *__restrict__ ov = a.fv[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
-    if (gy < H && gxb < W) {
-        size_t i = (size_t)gy * W + gxb;
-        if (((W & 3) == 0) && gxb + 3 < W) {
-            float4 ru = make_float4(du[0], du[1], du[2], du[3]);
-            float4 rv = make_float4(dv[0], dv[1], dv[2], dv[3]);
-            if (MODE == MODE_ITER) {
-                // flow += d (lucas_kanade_pyramidal.py:209-210)
-                float4 pu = *reinterpret_cast<const float4 *>(a.fu[sel] + (size_t)b * plane + i);
-                float4 pv = *reinterpret_cast<const float4 *>(a.fv[sel] + (size_t)b * plane + i);
-                ru.x = pu.x + ru.x; ru.y = pu.y + ru.y; ru.z = pu.z + ru.z; ru.w = pu.w + ru.w;
-                rv.x = pv.x + rv.x; rv.y = pv.y + rv.y; rv.z = pv.z + rv.z; rv.w = pv.w + rv.w;
-            }
-            *reinterpret_cast<float4 *>(ou + i) = ru;
-            *reinterpret_cast<float4 *>(ov + i) = rv;
-        } else {
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                if (gxb + o < W) {
-                    float ru = du[o], rv = dv[o];
-                    if (MODE == MODE_ITER) {
-                        ru = a.fu[sel][(size_t)b * plane + i + o] + ru;
-                        rv = a.fv[sel][(size_t)b * plane + i + o] + rv;
-                    }
-                    ou[i + o] = ru;
-                    ov[i + o] = rv;
-                }
-            }
-        }
-    }
-
-    if (MODE == MODE_ITER) {
-        // fixed-order block reduction of the |d| sums (fp64)
-        __shared__ double s_red[2][kLkThreads / 64];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            su += __shfl_down(su, off, 64);
-            sv += __shfl_down(sv, off, 64);
-        }
-        if ((tid & 63) == 0) {
-            s_red[0][tid >> 6] = su;
-            s_red[1][tid >> 6] = sv;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double tu = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
-            double tv = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
-            size_t nblk = (size_t)gridDim.x * gridDim.y;
-            size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-            a.partial[((size_t)b * nblk + blk) * 2 + 0] = tu;
-            a.partial[((size_t)b * nblk + blk) * 2 + 1] = tv;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// K1/K7 specialised for the 5x5 window (window_size 4 or 5): the hot kernel.
+// K1/K7: the fused kernel k_lkw<HW, MODE, VEC>; the 5x5 window (window_size 4 or 5) is the
+// hot case and has a specialised sum stage.
 //
 // Tile 64 x 32 per 256-thread block, each thread 2 (x) x 4 (y) outputs.
 //
@@ -573,6 +328,46 @@ __device__ __forceinline__ void patch5_sums(LoadRow load_row, T (&out)[NY][2])
     }
 }
 
+// Window sums of NX adjacent outputs of ONE output row for any window with
+// (2HW+1)^2 <= 128, in NumPy's pairwise order (r[t % 8] += a[t] for t < N - N % 8, the
+// fixed tree, then the tail).  `load_row(i, row)` fills row[0 .. NX+2HW-1] with products
+// P[y-HW+i][x0-HW .. x0+NX-1+HW].  Used for the 3x3 and 7x7 windows (the 5x5 window has
+// the cheaper shared-r form above).
+template <typename T, int HW, int NX, typename LoadRow>
+__device__ __forceinline__ void window_sums_row(LoadRow load_row, T (&out)[NX])
+{
+    constexpr int S = 2 * HW + 1, N = S * S, NB = N - (N % 8);
+    static_assert(N >= 8 && N <= 128, "window must fit NumPy's unrolled pairwise block");
+    T r[NX][8];
+    T res[NX];
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+        T row[NX + 2 * HW];
+        load_row(i, row);
+#pragma unroll
+        for (int c = 0; c < S; c++) {
+            const int t = S * i + c;
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                if (t < 8) {
+                    r[x][t] = row[x + c];
+                } else if (t < NB) {
+                    r[x][t % 8] = r[x][t % 8] + row[x + c];
+                } else {
+                    if (t == NB)
+                        res[x] = ((r[x][0] + r[x][1]) + (r[x][2] + r[x][3])) + ((r[x][4] + r[x][5]) + (r[x][6] + r[x][7]));
+                    res[x] = res[x] + row[x + c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        out[x] = zero_of<T>() + res[x];  // np.sum starts from the identity 0
+        pin(out[x]);
+    }
+}
+
 // Stage 1 works on groups of four horizontally adjacent cells: the staging tiles are
 // 38 rows x 72 columns starting at (y0-3, x0-4), so with W % 4 == 0 every group is one
 // aligned 16-byte load per plane (a group lies entirely inside or entirely outside the
@@ -580,16 +375,18 @@ __device__ __forceinline__ void patch5_sums(LoadRow load_row, T (&out)[NY][2])
 constexpr int k5GW = 18;                 // groups per staging row
 constexpr int k5AS = 4 * k5GW;           // 72 staging columns
 
-template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void k_lk5(LkArgs a)
+template <int HW, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_lkw(LkArgs a)
 {
-    constexpr int HW = 2, R = 3;
-    constexpr int AH = k5TY + 2 * R;                       // 38 staging rows (y0-3 ..)
+    static_assert(HW >= 1 && HW <= 3, "staging tile starts at x0-4: halo HW+1 <= 4");
+    constexpr int R = HW + 1;                              // halo of the frame-average tile
+    constexpr int AH = k5TY + 2 * R;                       // staging rows (y0-R ..)
     constexpr int AS = k5AS;                               // 72 staging columns (x0-4 ..)
-    constexpr int PH = k5TY + 2 * HW, PW = k5TX + 2 * HW;  // 36 x 68 product tile (y0-2, x0-2)
-    constexpr int NG = (PH * PW + 255) / 256;              // gradient pixels per thread (10)
-    constexpr int NGRP = AH * k5GW;                        // 684 groups of 4 cells
-    constexpr int NV = (NGRP + 255) / 256;                 // groups per thread (3)
+    constexpr int PH = k5TY + 2 * HW, PW = k5TX + 2 * HW;  // product tile at (y0-HW, x0-HW)
+    constexpr int NG = (PH * PW + 255) / 256;              // gradient pixels per thread
+    constexpr int NGRP = AH * k5GW;                        // groups of 4 staging cells
+    constexpr int NV = (NGRP + 255) / 256;                 // groups per thread
+    constexpr int GC = 4 - HW;                             // staging column of gradient column 0
 
     // one LDS block: [PA float2 | PB float2 | PC float]; avg and It alias its start
     __shared__ __attribute__((aligned(16))) float s_mem[PH * PW * 5];
@@ -646,10 +443,11 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             // thread's NE cells go out first, then the gathers in batches of BATCH cells.
             // Cell k of a thread is e = tid + 256 k; (row, col) advance by (3, 46) with carry
             // at 70 columns, which avoids a division per cell.
-            constexpr int AW = k5TX + 2 * R;                 // 70 cells per row (x0-3 ..)
-            constexpr int NE = (AH * AW + 255) / 256;        // 11 cells per thread
+            constexpr int AW = k5TX + 2 * R;                 // cells per row (x0-R ..)
+            constexpr int NE = (AH * AW + 255) / 256;        // cells per thread
             constexpr int BATCH = OFLK_BATCH;
-            static_assert(256 == 3 * AW + 46, "cell stepping assumes 70-column rows");
+            constexpr int QS = 256 / AW, RS = 256 % AW;      // row / column advance per 256 cells
+            constexpr int SC = 4 - R;                        // staging column of cell column 0
             const int r0 = tid / AW, c0 = tid - r0 * AW;
             const int Hm1 = H - 1, Wm1 = W - 1;
             float p[NE], q[NE], uu[NE], vv[NE];
@@ -663,7 +461,7 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
                     p[k] = prev[i];
                     uu[k] = fu_in[i];
                     vv[k] = fv_in[i];
-                    c += 46; r += 3;
+                    c += RS; r += QS;
                     if (c >= AW) { c -= AW; r += 1; }
                 }
             }
@@ -682,7 +480,7 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
                             // two 8-byte gathers per cell (the x pair of each tap row)
                             pr0[j] = *reinterpret_cast<const PairF *>(curr + tp[j].row0);
                             pr1[j] = *reinterpret_cast<const PairF *>(curr + tp[j].row1);
-                            c += 46; r += 3;
+                            c += RS; r += QS;
                             if (c >= AW) { c -= AW; r += 1; }
                         }
                     }
@@ -697,10 +495,10 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
                 for (int k = 0; k < NE; k++) {
                     if (r < AH) {
                         float sum = p[k] + q[k];
-                        s_avg[r * AS + c + 1] = sum * 0.5f;   // staging column = cell column + 1
-                        s_it[r * AS + c + 1] = p[k] - q[k];
+                        s_avg[r * AS + c + SC] = sum * 0.5f;
+                        s_it[r * AS + c + SC] = p[k] - q[k];
                     }
-                    c += 46; r += 3;
+                    c += RS; r += QS;
                     if (c >= AW) { c -= AW; r += 1; }
                 }
             }
@@ -784,8 +582,8 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             int e = tid + k * 256;
             if (e >= PH * PW) e = PH * PW - 1;  // tail threads recompute the last cell
             int r = e / PW, c = e - r * PW;
-            // gradient cell (r, c) = image (y0-2+r, x0-2+c) = staging cell (r+1, c+2)
-            const float *ap = &s_avg[(r + 1) * AS + (c + 2)];
+            // gradient cell (r, c) = image (y0-HW+r, x0-HW+c) = staging cell (r+1, c+GC)
+            const float *ap = &s_avg[(r + 1) * AS + (c + GC)];
             float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
             float a_0m = ap[-1], a_0p = ap[1];
             float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
@@ -803,7 +601,7 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
             iy = fmaf(a_mm, 0.125f, iy);
             gix[k] = ix;
             giy[k] = iy;
-            git[k] = s_it[(r + 1) * AS + (c + 2)];
+            git[k] = s_it[(r + 1) * AS + (c + GC)];
         }
         __syncthreads();  // everyone is done reading avg / It: the planes may overwrite them
     }
@@ -824,44 +622,49 @@ __global__ __launch_bounds__(256) void k_lk5(LkArgs a)
     // thread = 2 (x) by 4 (y) outputs; a half-wave spans one tile row, so the
     // 16-byte LDS reads of 32 adjacent lanes are contiguous (conflict-free)
     constexpr int NY = k5NY;
+    constexpr int RW = 2 + 2 * HW;   // product columns a thread reads per row
     const int tx = tid & 31, ty = tid >> 5;
     float2 sA[NY][2], sB[NY][2];
     float sC[NY][2];
-    {
-        const float2 *base = &s_pa[(NY * ty) * PW + 2 * tx];
-        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) {
-            const float4 *r4 = reinterpret_cast<const float4 *>(base + i * PW);
+    // rows of the interleaved planes: RW float2 = RW/2 aligned 16-byte reads; RW floats = RW/2 8-byte reads
+    auto load_f2 = [](const float2 *src, float2 (&row)[RW]) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(src);
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float4 q = r4[j];
-                row[2 * j] = make_float2(q.x, q.y);
-                row[2 * j + 1] = make_float2(q.z, q.w);
-            }
-        }, sA);
-    }
-    {
-        const float2 *base = &s_pb[(NY * ty) * PW + 2 * tx];
-        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) {
-            const float4 *r4 = reinterpret_cast<const float4 *>(base + i * PW);
+        for (int j = 0; j < RW / 2; j++) {
+            float4 q = r4[j];
+            row[2 * j] = make_float2(q.x, q.y);
+            row[2 * j + 1] = make_float2(q.z, q.w);
+        }
+    };
+    auto load_f1 = [](const float *src, float (&row)[RW]) {
+        const float2 *r2 = reinterpret_cast<const float2 *>(src);
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float4 q = r4[j];
-                row[2 * j] = make_float2(q.x, q.y);
-                row[2 * j + 1] = make_float2(q.z, q.w);
-            }
-        }, sB);
-    }
-    {
-        const float *base = &s_pc[(NY * ty) * PW + 2 * tx];
-        patch5_sums<float, NY>([&](int i, float (&row)[6]) {
-            const float2 *r2 = reinterpret_cast<const float2 *>(base + i * PW);
+        for (int j = 0; j < RW / 2; j++) {
+            float2 q = r2[j];
+            row[2 * j] = q.x;
+            row[2 * j + 1] = q.y;
+        }
+    };
+    if constexpr (HW == 2) {
+        const float2 *ba = &s_pa[(NY * ty) * PW + 2 * tx];
+        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(ba + i * PW, row); }, sA);
+        const float2 *bb = &s_pb[(NY * ty) * PW + 2 * tx];
+        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
+        const float *bc = &s_pc[(NY * ty) * PW + 2 * tx];
+        patch5_sums<float, NY>([&](int i, float (&row)[6]) { load_f1(bc + i * PW, row); }, sC);
+    } else {
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float2 q = r2[j];
-                row[2 * j] = q.x;
-                row[2 * j + 1] = q.y;
-            }
-        }, sC);
+        for (int oy = 0; oy < NY; oy++) {
+            const float2 *ba = &s_pa[(NY * ty + oy) * PW + 2 * tx];
+            window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(ba + i * PW, row); }, sA[oy]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float2 *bb = &s_pb[(NY * ty + oy) * PW + 2 * tx];
+            window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(bb + i * PW, row); }, sB[oy]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float *bc = &s_pc[(NY * ty + oy) * PW + 2 * tx];
+            window_sums_row<float, HW, 2>([&](int i, float (&row)[RW]) { load_f1(bc + i * PW, row); }, sC[oy]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     const int gxb = x0 + 2 * tx;
