@@ -112,3 +112,34 @@ def test_hip_other_presets_equal_reference(suite, golden_dir, name, preset):
     p, c = z["frame_0"].astype(np.float32), z[f"frame_1__{name}"].astype(np.float32)
     u, v = P.lucas_kanade_pyramidal(p, c, ref["levels"], ref["window_size"], ref["iterations"])
     assert digest(u) == ref["u_sha256"] and digest(v) == ref["v_sha256"]
+
+
+def test_demo_clis_on_rtl_frames(tmp_path, golden_dir, monkeypatch, capsys):
+    """the two demo CLIs (reference lucas_kanade_reference.py / lucas_kanade_pyramidal.py main) on
+    the frame pair the reference commits for its RTL testbench: raw float32 dumps equal the
+    reference's flow (digests), region means equal the recorded answers"""
+    import sys
+
+    import lucas_kanade_pyramidal as P
+    import lucas_kanade_reference as C
+
+    r = np.load(golden_dir / "rtl_frames.npz")
+    fdir = tmp_path / "frames"
+    fdir.mkdir()
+    r["natural__frame_00"].tofile(fdir / "frame_00.bin")
+    r["natural__frame_01"].tofile(fdir / "frame_01.bin")
+    out = tmp_path / "out"
+    monkeypatch.setattr(sys, "argv", ["lucas_kanade_reference.py", "--frame-dir", str(fdir), "--output-dir", str(out)])
+    monkeypatch.setattr(C, "visualize_flow", lambda *a, **k: None)
+    C.main()
+    u = np.fromfile(out / "flow_u.bin", np.float32).reshape(240, 320)
+    v = np.fromfile(out / "flow_v.bin", np.float32).reshape(240, 320)
+    sha = list(r["natural__sha"])
+    assert [digest(u), digest(v)] == sha[:2]
+    assert np.mean(u[105:135, 55:85]) == r["natural__answers"][0]
+    monkeypatch.setattr(sys, "argv", ["lucas_kanade_pyramidal.py", "--frame-dir", str(fdir), "--output-dir", str(out)])
+    P.main()
+    up = np.fromfile(out / "flow_u_pyramidal.bin", np.float32).reshape(240, 320)
+    vp = np.fromfile(out / "flow_v_pyramidal.bin", np.float32).reshape(240, 320)
+    assert [digest(up), digest(vp)] == sha[2:]
+    assert "Mean flow in test region" in capsys.readouterr().out

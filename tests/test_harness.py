@@ -115,3 +115,17 @@ def test_flow_metrics_definitions():
     mask = np.zeros((2, 2), bool)
     mask[0, 0] = True
     assert M.mean_absolute_error(u, v, 2.0, 0.0, mask) == (1.0, 0.0)
+
+
+def test_flow_text_dump_format(tmp_path):
+    """`x y u v` dump shared with scripts/visualize_flow.py and the RTL testbench (reference
+    lucas_kanade_reference.py:78-103)"""
+    import lucas_kanade_reference as C
+
+    u = np.arange(6, dtype=np.float32).reshape(2, 3) / 4
+    v = -u
+    C.export_flow_field_txt(u, v, tmp_path / "f.txt", 3, 2, {"x_min": 0, "x_max": 1, "y_min": 0, "y_max": 1})
+    lines = (tmp_path / "f.txt").read_text().splitlines()
+    assert lines[:4] == ["# Optical flow field data (Python reference)", "# Format: x y u v", "# Image size: 3x2",
+                         "# Test region: x[0:1], y[0:1]"]
+    assert lines[4] == "0 0 0.000000 -0.000000" and lines[-1] == "2 1 1.250000 -1.250000" and len(lines) == 10
