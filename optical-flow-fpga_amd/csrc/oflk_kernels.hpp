@@ -103,6 +103,7 @@ __device__ __forceinline__ int clamp0(int x, int hi)
 struct LeanTaps {
     unsigned row0, row1;  // offsets of the two 2-pixel tap pairs (x pair starts at xb = min(x0, W-2))
     bool swap;            // x0 == W-1: the pair is (x0-1, x0); tap x0 is its second element
+    bool single;          // W == 1: the second element of the pair lies outside the row, ignore it
     double wy0, wy1, wx0, wx1;
     bool inside;
 };
@@ -133,6 +134,7 @@ __device__ __forceinline__ LeanTaps lean_taps(int H, int W, int gy, int gx, floa
     const int y0c = t.inside ? y0 : 0;
     const int y1c = t.inside ? ((y0 + 1 < H) ? y0 + 1 : max(H - 2, 0)) : 0;
     t.swap = t.inside && lastx && W > 1;
+    t.single = W == 1;
     t.row0 = (unsigned)(y0c * W + xb);
     t.row1 = (unsigned)(y1c * W + xb);
     return t;
@@ -140,8 +142,12 @@ __device__ __forceinline__ LeanTaps lean_taps(int H, int W, int gy, int gx, floa
 
 __device__ __forceinline__ float lean_finish(const LeanTaps &t, PairF r0, PairF r1)
 {
-    const float p00 = t.swap ? r0.b : r0.a, p01 = t.swap ? r0.a : r0.b;
-    const float p10 = t.swap ? r1.b : r1.a, p11 = t.swap ? r1.a : r1.b;
+    float p00 = t.swap ? r0.b : r0.a, p01 = t.swap ? r0.a : r0.b;
+    float p10 = t.swap ? r1.b : r1.a, p11 = t.swap ? r1.a : r1.b;
+    if (t.single) {  // one-column image: the x+1 tap is the mirrored (same) element, weight 0
+        p01 = p00;
+        p11 = p10;
+    }
     double acc = 0.0, c;
     c = (double)p00; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
     c = (double)p01; c = c * t.wy0; c = c * t.wx1; acc = acc + c;

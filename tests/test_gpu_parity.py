@@ -120,6 +120,14 @@ def test_warp_matches_oracle(P, oracle):
     _eq(P.warp_image(img, u, v), oracle.warp_image(img, u, v), "warp")
     z = np.zeros_like(img)
     _eq(P.warp_image(img, z, z), img, "identity warp")
+    # degenerate shapes: one column, one row, one pixel
+    for shape in ((9, 1), (1, 9), (1, 1), (2, 2)):
+        im = rng.normal(50, 20, shape).astype(np.float32)
+        uu = rng.normal(0, 1, shape).astype(np.float32)
+        vv = rng.normal(0, 1, shape).astype(np.float32)
+        uu.flat[0] = 0.0
+        vv.flat[0] = 0.0
+        _eq(P.warp_image(im, uu, vv), oracle.warp_image(im, uu, vv), f"warp {shape}")
 
 
 @pytest.mark.parametrize("cshape,tshape", [((60, 80), (120, 160)), ((37, 53), (75, 107)), ((9, 13), (18, 26)),
