@@ -146,7 +146,7 @@ def main() -> None:
                     traffic = tr["hbm_bytes_per_launch"]
             except Exception:
                 pass
-        roofline = {"bound": "hbm", "kernel": "k_lk5<ITER> (fused LK iteration, finest level)",
+        roofline = {"bound": "hbm", "kernel": "k_lkw<2,ITER> (fused LK iteration, finest level)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": bytes_per_launch}

@@ -20,14 +20,14 @@ def per_launch(sub, counter):
     rows = []
     for f in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_lk5<1" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if "k_lkw<2, 1" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     big = max(g for g, _ in rows)                       # finest level = largest grid
     vals = [v for g, v in rows if g == big]
     return sum(vals) / len(vals), len(vals), big
 fetch, nf, grid = per_launch("fetch", "FETCH_SIZE")
 write, nw, _ = per_launch("write", "WRITE_SIZE")
-res = {"kernel": "k_lk5<MODE_ITER> finest level", "pairs": 32, "shape": [1080, 1920], "grid_size": grid, "launches_averaged": [nf, nw],
+res = {"kernel": "k_lkw<2, MODE_ITER> finest level", "pairs": 32, "shape": [1080, 1920], "grid_size": grid, "launches_averaged": [nf, nw],
        "FETCH_SIZE_raw_units_1024B": fetch, "WRITE_SIZE_raw_units_1024B": write,
        "fetch_bytes_corrected_x2": fetch * 1024 * 2, "write_bytes": write * 1024,
        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
