@@ -177,6 +177,7 @@ struct oflk_plan {
     GaussW gauss;
     // profiling
     bool prof = false;
+    int prof_only = -1;  // >= 0: bracket only launches of this kernel class
     struct Ev { hipEvent_t a, b; int cls; };
     std::vector<Ev> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -202,6 +203,7 @@ struct Prof {
     Prof(oflk_plan *p_, hipStream_t s_, int cls_) : p(p_), s(s_), cls(cls_)
     {
         if (!p || !p->prof) return;
+        if (p->prof_only >= 0 && cls != p->prof_only) return;
         if (p->pool.empty()) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
@@ -631,6 +633,7 @@ OFLK_API int oflk_plan_set_profiling(oflk_plan *p, int enabled)
 {
     if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
     p->prof = enabled != 0;
+    p->prof_only = enabled == 2 ? KC_LK_ITER_FINEST : -1;  // 2: only the dominant kernel
     for (auto &e : p->pending) p->pool.push_back({e.a, e.b});
     p->pending.clear();
     for (int i = 0; i < KC_COUNT; i++) {

@@ -155,8 +155,9 @@ class Plan:
         check(lib().oflk_plan_read_log(self._h, ptr(log), runs.ctypes.data_as(_i32p), stream))
         return log, runs
 
-    def set_profiling(self, enabled: bool) -> None:
-        check(lib().oflk_plan_set_profiling(self._h, 1 if enabled else 0))
+    def set_profiling(self, enabled) -> None:
+        """False/0 off, True/1 every kernel, 2 only the dominant kernel (finest-level LK iteration)."""
+        check(lib().oflk_plan_set_profiling(self._h, int(enabled)))
 
     def kernel_times(self) -> dict:
         n = 32

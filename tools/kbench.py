@@ -39,6 +39,14 @@ def main():
         for _ in range(2):
             call(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
         torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            call(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"== {name} without per-kernel events: {e0.elapsed_time(e1) / args.reps * 1e3:.1f} us/call")
         plan.set_profiling(True)
         t0 = torch.cuda.Event(enable_timing=True)
         t1 = torch.cuda.Event(enable_timing=True)
