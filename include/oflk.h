@@ -104,6 +104,19 @@ int oflk_pyramidal_batch(const float *prev, const float *curr, int B, int H, int
                          int window_size, int iters, float *u, float *v, float *residual_log,
                          int *iters_run);
 
+/* ---- uint8 frames (the reference's on-disk format) ------------------------- */
+/* Same as the batch entry points, for raw 8-bit frames [B][H][W] as generate_test_suite.py
+ * writes them (frame_0x.bin, :259-261).  The uint8 -> float32 conversion the verifier does
+ * on the host (python/optical_flow_verifier.py:61-65) runs on the device; results are
+ * identical to converting first. */
+int oflk_single_scale_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
+                         int window_size, float *u, float *v);
+int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
+                      int levels, int window_size, int iters, float *u, float *v, float *residual_log,
+                      int *iters_run);
+/* device-side conversion for pipelines that hold uint8 frames in HBM: d_out[i] = (float)d_in[i] */
+int oflk_u8_to_f32(const unsigned char *d_in, float *d_out, size_t n, void *stream);
+
 /* ---- device-resident plan API (pipelines, bench) -------------------------- */
 typedef struct oflk_plan oflk_plan;
 

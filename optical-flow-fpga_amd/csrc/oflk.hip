@@ -789,6 +789,90 @@ OFLK_API int oflk_pyramidal_batch(const float *prev, const float *curr, int B, i
     return oflk_plan_read_log(p, residual_log, iters_run, nullptr);
 }
 
+// ---- uint8 ingestion: raw 8-bit frames as the reference stores them (frame_0x.bin,
+// generate_test_suite.py:259-261); the uint8 -> float32 conversion the verifier performs
+// on the host (optical_flow_verifier.py:61-65) runs on the device instead ----------------
+namespace {
+unsigned char *g_u8[2] = {nullptr, nullptr};
+size_t g_u8_elems = 0;
+
+int stage_u8(const unsigned char *prev, const unsigned char *curr, size_t n)
+{
+    if (n > g_u8_elems) {
+        for (auto &q : g_u8) {
+            if (q) (void)hipFree(q);
+            q = nullptr;
+        }
+        g_u8_elems = 0;
+        size_t tot = 0;
+        for (auto &q : g_u8) {
+            int rc = dmalloc(&q, n, &tot);
+            if (rc) return rc;
+        }
+        g_u8_elems = n;
+    }
+    HIP_TRY(hipMemcpyAsync(g_u8[0], prev, n, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(g_u8[1], curr, n, hipMemcpyHostToDevice, nullptr));
+    dim3 grid((unsigned)((n + 4095) / 4096));
+    hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, nullptr, (const unsigned char *)g_u8[0], g_io[0], n);
+    hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, nullptr, (const unsigned char *)g_u8[1], g_io[1], n);
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+}  // namespace
+
+OFLK_API int oflk_single_scale_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
+                                  int window_size, float *u, float *v)
+{
+    int rc = check_hw(prev, curr, H, W);
+    if (rc) return rc;
+    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    std::lock_guard<std::mutex> lk(g_mu);
+    oflk_plan *p = nullptr;
+    rc = host_plan(B, H, W, 1, window_size, 0, &p);
+    if (rc) return rc;
+    size_t n = (size_t)B * H * W, bytes = n * sizeof(float);
+    if ((rc = stage_u8(prev, curr, n))) return rc;
+    rc = oflk_plan_single_scale(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
+                               int levels, int window_size, int iters, float *u, float *v,
+                               float *residual_log, int *iters_run)
+{
+    int rc = check_hw(prev, curr, H, W);
+    if (rc) return rc;
+    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    std::lock_guard<std::mutex> lk(g_mu);
+    oflk_plan *p = nullptr;
+    rc = host_plan(B, H, W, levels, window_size, iters, &p);
+    if (rc) return rc;
+    size_t n = (size_t)B * H * W, bytes = n * sizeof(float);
+    if ((rc = stage_u8(prev, curr, n))) return rc;
+    rc = oflk_plan_pyramidal(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    return oflk_plan_read_log(p, residual_log, iters_run, nullptr);
+}
+
+OFLK_API int oflk_u8_to_f32(const unsigned char *d_in, float *d_out, size_t n, void *stream)
+{
+    if (!d_in || !d_out) return fail(OFLK_ERR_INVALID, "NULL argument");
+    if (n == 0) return OFLK_OK;
+    dim3 grid((unsigned)((n + 4095) / 4096));
+    hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
 OFLK_API int oflk_pyramidal(const float *prev, const float *curr, int H, int W, int levels,
                             int window_size, int iters, float *u, float *v, float *residual_log,
                             int *iters_run)

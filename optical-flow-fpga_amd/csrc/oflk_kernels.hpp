@@ -1240,6 +1240,27 @@ __global__ __launch_bounds__(256) void k_gradients(const float *__restrict__ pre
     It[i] = prev[i] - curr[i];
 }
 
+// uint8 frames -> float32 (the conversion the verifier does on the host,
+// optical_flow_verifier.py:61-65; exact for every uint8 value).  16 pixels per thread.
+__global__ __launch_bounds__(256) void k_u8_to_f32(const unsigned char *__restrict__ in, float *__restrict__ out,
+                                                   size_t n)
+{
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i + 16 <= n && ((reinterpret_cast<uintptr_t>(in + i) & 15) == 0)) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float4 f = make_float4((float)(w[k] & 255u), (float)((w[k] >> 8) & 255u), (float)((w[k] >> 16) & 255u),
+                                   (float)(w[k] >> 24));
+            *reinterpret_cast<float4 *>(out + i + 4 * k) = f;
+        }
+    } else {
+        for (int k = 0; k < 16; k++)
+            if (i + k < n) out[i + k] = (float)in[i + k];
+    }
+}
+
 // copy the finest-level flow of pairs whose result did not land in the caller's
 // buffers (early exit changed the ping-pong parity); no-op blocks otherwise
 struct ExportArgs {

@@ -44,6 +44,9 @@ SIGNATURES = {
     "oflk_pyramidal": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
     "oflk_single_scale_batch": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
     "oflk_pyramidal_batch": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
+    "oflk_single_scale_u8": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
+    "oflk_pyramidal_u8": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
+    "oflk_u8_to_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
     "oflk_plan_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "oflk_plan_destroy": (ctypes.c_int, [_vp]),
     "oflk_plan_workspace_bytes": (ctypes.c_size_t, [_vp]),
@@ -104,6 +107,12 @@ def as_f32(a) -> np.ndarray:
     if arr.ndim != 2:
         raise ValueError(f"expected a 2-D array, got shape {arr.shape}")
     return arr
+
+
+def both_u8(a, b) -> bool:
+    """True when both frames are 2-D uint8 arrays (the reference's .bin frame format)."""
+    return (isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and a.dtype == np.uint8 and b.dtype == np.uint8
+            and a.ndim == 2 and b.ndim == 2)
 
 
 def ptr(a: np.ndarray):

@@ -46,6 +46,15 @@ def lucas_kanade_single_scale(
 
     Replaces reference lucas_kanade_core.py:48-70 (oflk_single_scale).
     """
+    if _oflk.both_u8(frame_prev, frame_curr):
+        # raw 8-bit frames: converted on the device (same values as .astype(np.float32) first)
+        p, c = np.ascontiguousarray(frame_prev), np.ascontiguousarray(frame_curr)
+        H, W = _oflk.same_shape(p, c)
+        u = np.empty((H, W), np.float32)
+        v = np.empty((H, W), np.float32)
+        _oflk.check(_oflk.lib().oflk_single_scale_u8(p.ctypes.data, c.ctypes.data, 1, H, W, int(window_size),
+                                                     _oflk.ptr(u), _oflk.ptr(v)))
+        return u, v
     p, c = _oflk.as_f32(frame_prev), _oflk.as_f32(frame_curr)
     H, W = _oflk.same_shape(p, c)
     u = np.empty((H, W), np.float32)

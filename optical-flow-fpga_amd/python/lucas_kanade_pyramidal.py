@@ -111,12 +111,22 @@ def lucas_kanade_pyramidal_with_log(
     residual_log[l, k] = (mean|du|, mean|dv|) of iteration k at level l (coarse first);
     iters_run[l] = iterations executed at level l.
     """
+    log = np.zeros((max(num_levels, 1), max(num_iterations, 1), 2), np.float32)
+    runs = np.zeros(max(num_levels, 1), np.int32)
+    if _oflk.both_u8(frame_prev, frame_curr):
+        # raw 8-bit frames: converted on the device (same values as .astype(np.float32) first)
+        p, c = np.ascontiguousarray(frame_prev), np.ascontiguousarray(frame_curr)
+        H, W = _oflk.same_shape(p, c)
+        u = np.empty((H, W), np.float32)
+        v = np.empty((H, W), np.float32)
+        _oflk.check(_oflk.lib().oflk_pyramidal_u8(p.ctypes.data, c.ctypes.data, 1, H, W, int(num_levels),
+                                                  int(window_size), int(num_iterations), _oflk.ptr(u),
+                                                  _oflk.ptr(v), _oflk.ptr(log), runs.ctypes.data_as(_i32p)))
+        return u, v, log, runs
     p, c = _oflk.as_f32(frame_prev), _oflk.as_f32(frame_curr)
     H, W = _oflk.same_shape(p, c)
     u = np.empty((H, W), np.float32)
     v = np.empty((H, W), np.float32)
-    log = np.zeros((max(num_levels, 1), max(num_iterations, 1), 2), np.float32)
-    runs = np.zeros(max(num_levels, 1), np.int32)
     _oflk.check(_oflk.lib().oflk_pyramidal(_oflk.ptr(p), _oflk.ptr(c), H, W, int(num_levels),
                                            int(window_size), int(num_iterations), _oflk.ptr(u),
                                            _oflk.ptr(v), _oflk.ptr(log), runs.ctypes.data_as(_i32p)))

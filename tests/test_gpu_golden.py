@@ -143,3 +143,24 @@ def test_demo_clis_on_rtl_frames(tmp_path, golden_dir, monkeypatch, capsys):
     vp = np.fromfile(out / "flow_v_pyramidal.bin", np.float32).reshape(240, 320)
     assert [digest(up), digest(vp)] == sha[2:]
     assert "Mean flow in test region" in capsys.readouterr().out
+
+
+def test_uint8_ingestion_equals_float_path(suite):
+    """raw 8-bit frames (the reference's .bin format) through oflk_*_u8: same flow as converting on the host"""
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+
+    z, ref = suite
+    p8, c8 = z["frame_0"], z["frame_1__translate_rotate"]
+    r = ref["patterns"]["translate_rotate"]
+    u, v = K.lucas_kanade_single_scale(p8, c8, 5)
+    assert digest(u) == r["single_scale"]["u_sha256"] and digest(v) == r["single_scale"]["v_sha256"]
+    u, v = P.lucas_kanade_pyramidal(p8, c8, 3, 5, 3)
+    assert digest(u) == r["pyramidal"]["u_sha256"] and digest(v) == r["pyramidal"]["v_sha256"]
+    # odd sizes / unaligned tails of the conversion kernel
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    b = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    u8 = K.lucas_kanade_single_scale(a, b, 5)
+    uf = K.lucas_kanade_single_scale(a.astype(np.float32), b.astype(np.float32), 5)
+    assert np.array_equal(u8[0], uf[0]) and np.array_equal(u8[1], uf[1])
