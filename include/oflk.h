@@ -39,7 +39,7 @@ extern "C" {
 #define OFLK_ERR_NOMEM (-5)       /* device or host allocation failed */
 
 #define OFLK_MAX_LEVELS 16
-#define OFLK_MAX_WINDOW 7 /* largest window_size with a compiled kernel (3x3, 5x5, 7x7; even sizes round down like the reference) */
+#define OFLK_MAX_WINDOW 11 /* largest window_size with a compiled kernel (3x3 ... 11x11; even sizes round down like the reference) */
 
 /* ---- library ------------------------------------------------------------ */
 const char *oflk_version(void);

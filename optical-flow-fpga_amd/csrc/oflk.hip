@@ -144,9 +144,9 @@ int window_hw(int window_size, int *hw)
 {
     if (window_size < 1) return fail(OFLK_ERR_INVALID, "window_size must be >= 1");
     int h = window_size / 2;  // even sizes round down, lucas_kanade_core.py:104
-    if (h < 1 || h > 3)
+    if (h < 1 || h > 5)
         return fail(OFLK_ERR_UNSUPPORTED,
-                    "window_size %d not built (kernels exist for 3x3, 5x5, 7x7 windows)", window_size);
+                    "window_size %d not built (kernels exist for 3x3 ... 11x11 windows)", window_size);
     *hw = h;
     return OFLK_OK;
 }
@@ -240,6 +240,8 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         case 1: OFLK_LAUNCH_LKW(1); break;
         case 2: OFLK_LAUNCH_LKW(2); break;
         case 3: OFLK_LAUNCH_LKW(3); break;
+        case 4: OFLK_LAUNCH_LKW(4); break;
+        case 5: OFLK_LAUNCH_LKW(5); break;
         default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
     }
 #undef OFLK_LAUNCH_LKW

@@ -378,21 +378,26 @@ __device__ __forceinline__ void window_sums_row(LoadRow load_row, T (&out)[NX])
 // 38 rows x 72 columns starting at (y0-3, x0-4), so with W % 4 == 0 every group is one
 // aligned 16-byte load per plane (a group lies entirely inside or entirely outside the
 // image).  Other widths take the VEC = false instantiation (cell-by-cell loads).
-constexpr int k5GW = 18;                 // groups per staging row
-constexpr int k5AS = 4 * k5GW;           // 72 staging columns
+// staging tile geometry: columns start at x0 - SX (a multiple of 4 >= the halo HW+1)
+template <int HW> struct LkGeom {
+    static constexpr int SX = (HW + 1 <= 4) ? 4 : 8;   // staging column of image column x0
+    static constexpr int GW = (k5TX + 2 * SX) / 4;     // 4-cell groups per staging row (18 or 20)
+    static constexpr int AS = 4 * GW;                  // staging columns (72 or 80)
+};
 
 template <int HW, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
 {
-    static_assert(HW >= 1 && HW <= 3, "staging tile starts at x0-4: halo HW+1 <= 4");
+    static_assert(HW >= 1 && HW <= 5, "windows up to 11x11 (NumPy's single pairwise block)");
     constexpr int R = HW + 1;                              // halo of the frame-average tile
+    constexpr int SX = LkGeom<HW>::SX, k5GW = LkGeom<HW>::GW;
     constexpr int AH = k5TY + 2 * R;                       // staging rows (y0-R ..)
-    constexpr int AS = k5AS;                               // 72 staging columns (x0-4 ..)
+    constexpr int AS = LkGeom<HW>::AS;                     // staging columns (x0-SX ..)
     constexpr int PH = k5TY + 2 * HW, PW = k5TX + 2 * HW;  // product tile at (y0-HW, x0-HW)
     constexpr int NG = (PH * PW + 255) / 256;              // gradient pixels per thread
     constexpr int NGRP = AH * k5GW;                        // groups of 4 staging cells
     constexpr int NV = (NGRP + 255) / 256;                 // groups per thread
-    constexpr int GC = 4 - HW;                             // staging column of gradient column 0
+    constexpr int GC = SX - HW;                            // staging column of gradient column 0
 
     // one LDS block: [PA float2 | PB float2 | PC float]; avg and It alias its start
     __shared__ __attribute__((aligned(16))) float s_mem[PH * PW * 5];
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
             constexpr int NE = (AH * AW + 255) / 256;        // cells per thread
             constexpr int BATCH = OFLK_BATCH;
             constexpr int QS = 256 / AW, RS = 256 % AW;      // row / column advance per 256 cells
-            constexpr int SC = 4 - R;                        // staging column of cell column 0
+            constexpr int SC = SX - R;                       // staging column of cell column 0
             const int r0 = tid / AW, c0 = tid - r0 * AW;
             const int Hm1 = H - 1, Wm1 = W - 1;
             float p[NE], q[NE], uu[NE], vv[NE];
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                 g = min(g, NGRP - 1);
                 int r = g / k5GW, c4 = g - r * k5GW;
                 gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
-                gx = x0 - 4 + 4 * c4;
+                gx = x0 - SX + 4 * c4;
                 whole = VEC && gx >= 0 && gx + 3 < W;
             };
             auto load4 = [&](const float *__restrict__ src, int gy, int gx, bool whole) -> float4 {

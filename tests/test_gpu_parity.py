@@ -58,7 +58,7 @@ SHAPES = [(37, 53), (16, 64), (17, 65), (64, 256), (240, 320), (5, 5), (7, 9), (
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("win", [5, 3, 7, 4])
+@pytest.mark.parametrize("win", [5, 3, 7, 4, 9, 11])
 def test_single_scale_matches_oracle(K, oracle, shape, win):
     rng = np.random.default_rng(hash((shape, win)) & 0xFFFF)
     for integer in (False, True):
@@ -154,7 +154,8 @@ def _check_pyramidal(P, oracle, a, b, levels, win, iters):
 
 
 @pytest.mark.parametrize("shape,levels,win,iters", [((240, 320), 3, 5, 3), ((97, 131), 2, 5, 3), ((120, 160), 3, 7, 2),
-                                                    ((64, 80), 1, 5, 3), ((75, 75), 3, 3, 4), ((240, 320), 4, 5, 3)])
+                                                    ((64, 80), 1, 5, 3), ((75, 75), 3, 3, 4), ((240, 320), 4, 5, 3),
+                                                    ((120, 160), 2, 9, 2), ((96, 128), 2, 11, 2)])
 def test_pyramidal_matches_oracle_synthetic(P, oracle, shape, levels, win, iters):
     from oflk_synth import synth_pair
 
@@ -231,7 +232,7 @@ def test_errors_are_loud():
     with pytest.raises(ValueError):
         K_.lucas_kanade_single_scale(a, np.zeros((8, 9), np.float32))
     with pytest.raises(_oflk.OflkError):
-        K_.lucas_kanade_single_scale(a, a, 9)  # window not built -> explicit error, no fallback
+        K_.lucas_kanade_single_scale(a, a, 13)  # window not built -> explicit error, no fallback
 
 
 # ---- BASELINE.json full sizes ---------------------------------------------------
