@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -228,8 +229,45 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     LkArgs a = a_in;
     a.B = B;
     Prof pr(plan, s, cls);
-    // 1-D grid: the kernel decodes (pair, tile) in an XCD-aware order
-    dim3 grid((unsigned)(((a.W + k5TX - 1) / k5TX) * ((a.H + k5TY - 1) / k5TY) * B));
+    // 1-D grid.  Large launches chain vertically adjacent tiles in one block (they share 2R
+    // staging rows, the expensive part of stage 1): tile rows are cut into segments of `cap`
+    // rows, then ever shorter ones, and every XCD runs its segments longest first so that the
+    // drain of the grid is made of single tiles.  Small launches keep one tile per block.
+    const int tiles_x = (a.W + k5TX - 1) / k5TX, tiles_y = (a.H + k5TY - 1) / k5TY;
+    if (a.W <= 2 * hw || a.H <= 2 * hw) {
+        // nothing has a full window: all-zero d (and k_lkw may assume H, W > 2*hw)
+        const int ntiles = tiles_x * tiles_y;
+        const size_t work = std::max((size_t)a.H * (size_t)a.W, (size_t)ntiles * 2);
+        hipLaunchKernelGGL((k_lk_degenerate<MODE>), dim3((unsigned)((work + 255) / 256), (unsigned)B), dim3(256), 0, s, a,
+                           ntiles);
+        HIP_TRY(hipGetLastError());
+        return OFLK_OK;
+    }
+    static const int cap_env = getenv("OFLK_TPB") ? atoi(getenv("OFLK_TPB")) : 8;
+    const long resident = 1024;  // 256 CUs x 4 blocks
+    const long per_slot = (long)B * tiles_x * tiles_y / resident;
+    int cap = MODE == MODE_GRADS ? 1 : (int)std::min<long>(std::max(1, cap_env), per_slot / 5);
+    cap = std::max(cap, (tiles_y + kMaxSegs / 2 - 1) / (kMaxSegs / 2));  // keep the table short
+    if (MODE == MODE_GRADS || cap_env <= 1 || per_slot < 10) cap = 1;
+    unsigned nblocks;
+    if (cap <= 1) {
+        a.nseg = 0;
+        nblocks = (unsigned)(tiles_x * tiles_y * B);
+    } else {
+        int row = 0, n = 0;
+        while (row < tiles_y) {
+            const int rest = tiles_y - row;
+            int len = std::min(cap, std::max(1, rest / 3));
+            if (n == kMaxSegs - 1) len = rest;  // cannot happen for cap chosen above; stay in bounds
+            a.seg_row[n++] = (unsigned short)row;
+            row += len;
+        }
+        a.seg_row[n] = (unsigned short)tiles_y;
+        a.nseg = n;
+        const int strips = B * tiles_x;
+        nblocks = 8u * (unsigned)((strips + 7) / 8) * (unsigned)n;
+    }
+    dim3 grid(nblocks);
     const bool vec = (a.W & 3) == 0;
 #define OFLK_LAUNCH_LKW(HWV)                                                          \
     do {                                                                              \
@@ -428,8 +466,8 @@ OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, 
     *out = nullptr;
     if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
     if (iters < 0) return fail(OFLK_ERR_INVALID, "iters must be >= 0");
-    if ((size_t)H * (size_t)W > (size_t)0x7fffffff)
-        return fail(OFLK_ERR_UNSUPPORTED, "frames above 2^31 pixels are not supported");
+    if ((size_t)H * (size_t)W >= ((size_t)1 << 30) || H >= (1 << 24) || W >= (1 << 24))
+        return fail(OFLK_ERR_UNSUPPORTED, "frames of 2^30 pixels or more are not supported");  // 32-bit byte offsets
     int hw = 0;
     int rc = window_hw(window_size, &hw);
     if (rc) return rc;
@@ -734,8 +772,8 @@ int check_hw(const void *a, const void *b, int H, int W)
 {
     if (!a || !b) return fail(OFLK_ERR_INVALID, "NULL array argument");
     if (H < 1 || W < 1) return fail(OFLK_ERR_INVALID, "H and W must be >= 1 (got %d x %d)", H, W);
-    if ((size_t)H * (size_t)W > (size_t)0x7fffffff)
-        return fail(OFLK_ERR_UNSUPPORTED, "frames above 2^31 pixels are not supported");
+    if ((size_t)H * (size_t)W >= ((size_t)1 << 30) || H >= (1 << 24) || W >= (1 << 24))
+        return fail(OFLK_ERR_UNSUPPORTED, "frames of 2^30 pixels or more are not supported");  // 32-bit byte offsets
     return OFLK_OK;
 }
 

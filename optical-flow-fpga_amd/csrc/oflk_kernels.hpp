@@ -11,6 +11,7 @@
 // Reference line numbers are relative to /root/reference/python/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #pragma clang fp contract(off)
@@ -96,14 +97,49 @@ __device__ __forceinline__ int clamp0(int x, int hi)
     return r;
 }
 
-// Lean form of the same sampling for the fused iteration kernel: the four tap offsets
-// are one base plus two steps, and the range test runs on the integer floors
-// (y < 0 <=> floor(y) < 0;  y > H-1 <=> floor(y) > H-1, or floor(y) == H-1 with a
-// non-zero fraction).  Same values as bilinear_taps + bilinear_finish.
+// Lean form of the same sampling for the fused iteration kernel and k_warp.
+//   * the range test is two fp64 compares per axis on the coordinate itself;
+//   * the 2x2 taps are two 8-byte pairs at byte offsets off0 and off0 + rowstep from the
+//     plane base (32-bit offsets: a plane is < 4 GiB, checked on the host);
+//   * a sample exactly on the last row/column (fraction 0) is expressed from the
+//     previous cell instead: floor is capped at N-2, which makes the fraction exactly 1
+//     and the weights exactly (0, 1).  SciPy reads the same two elements there (the
+//     mirrored neighbour N-2 with weight 0); a zero product only moves inside the fp64
+//     sum, which cannot change a sum that starts at +0 (finite pixels).
+// Same values as bilinear_taps + bilinear_finish.
+struct LeanGeom {
+    double Hm1, Wm1;     // last valid coordinate
+    double Hm2, Wm2;     // cap of the floor: max(N-2, 0)
+    int W;
+    unsigned rowstep;    // bytes from tap row 0 to tap row 1: 4W, or 0 when H == 1
+    bool single;         // W == 1: the pair load would leave the row; taps are loaded one by one
+};
+
+// a wave-uniform double moved to scalar registers (int -> fp64 conversion only exists on
+// the vector ALU, and its result would otherwise occupy a VGPR pair for the whole kernel)
+__device__ __forceinline__ double uniform_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ LeanGeom lean_geom(int H, int W)
+{
+    LeanGeom g;
+    g.Hm1 = uniform_f64((double)(H - 1));
+    g.Wm1 = uniform_f64((double)(W - 1));
+    g.Hm2 = uniform_f64((double)max(H - 2, 0));
+    g.Wm2 = uniform_f64((double)max(W - 2, 0));
+    g.W = W;
+    g.rowstep = H > 1 ? 4u * (unsigned)W : 0u;
+    g.single = W == 1;
+    return g;
+}
+
 struct LeanTaps {
-    unsigned row0, row1;  // offsets of the two 2-pixel tap pairs (x pair starts at xb = min(x0, W-2))
-    bool swap;            // x0 == W-1: the pair is (x0-1, x0); tap x0 is its second element
-    bool single;          // W == 1: the second element of the pair lies outside the row, ignore it
+    unsigned off0;       // byte offset of the first pair; the second is off0 + rowstep
     double wy0, wy1, wx0, wx1;
     bool inside;
 };
@@ -112,47 +148,59 @@ struct LeanTaps {
 // accepts the unaligned dwordx2
 struct __attribute__((packed, aligned(4))) PairF { float a, b; };
 
-__device__ __forceinline__ LeanTaps lean_taps(int H, int W, int gy, int gx, float u, float v)
+// load at a uniform base plus a 32-bit byte offset (one SGPR pair + one VGPR: no 64-bit
+// address arithmetic on the vector ALU)
+template <class T>
+__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v)
+{
+    *reinterpret_cast<T *>(static_cast<char *>(base) + byte_off) = v;
+}
+
+__device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx, float u, float v)
 {
     LeanTaps t;
     const double y = (double)gy + (double)v;   // int64 + float32 -> float64, as the reference
     const double x = (double)gx + (double)u;
-    const double fy = floor(y), fx = floor(x);
-    const int y0 = (int)fy, x0 = (int)fx;      // saturating; NaN -> 0
+    // bitwise, not short-circuit: four compares and three scalar ANDs, no branches
+    t.inside = (y >= 0.0) & (y <= g.Hm1) & (x >= 0.0) & (x <= g.Wm1);
+    const double fy = fmin(floor(y), g.Hm2), fx = fmin(floor(x), g.Wm2);
     const double ry = y - fy, rx = x - fx;
-    t.inside = y0 >= 0 && x0 >= 0 && (y0 < H - 1 || (y0 == H - 1 && ry == 0.0)) &&
-               (x0 < W - 1 || (x0 == W - 1 && rx == 0.0));
     t.wy0 = 1.0 - ry;
     t.wx0 = 1.0 - rx;
     t.wy1 = 1.0 - t.wy0;
     t.wx1 = 1.0 - t.wx0;
-    // SciPy reads the mirrored neighbour (index N-2) with weight exactly 0 when a sample
-    // lands on the last index; any finite value gives the same result, so the x pair is
-    // simply shifted left by one there and the y pair re-reads row H-2
-    const bool lastx = x0 >= W - 1;
-    const int xb = t.inside ? (lastx ? max(W - 2, 0) : x0) : 0;
-    const int y0c = t.inside ? y0 : 0;
-    const int y1c = t.inside ? ((y0 + 1 < H) ? y0 + 1 : max(H - 2, 0)) : 0;
-    t.swap = t.inside && lastx && W > 1;
-    t.single = W == 1;
-    t.row0 = (unsigned)(y0c * W + xb);
-    t.row1 = (unsigned)(y1c * W + xb);
+    const int y0 = (int)fy, x0 = (int)fx;      // in range whenever `inside`
+    const unsigned cell = (unsigned)__mul24(y0, g.W) + (unsigned)x0;   // H, W < 2^24 (host check)
+    t.off0 = t.inside ? cell * 4u : 0u;
     return t;
+}
+
+// NARROW = false: the caller guarantees W >= 2 (and skips the one-column form)
+template <bool NARROW>
+__device__ __forceinline__ void lean_load(const LeanGeom &g, const float *__restrict__ img, const LeanTaps &t,
+                                          PairF &r0, PairF &r1)
+{
+    if (NARROW && g.single) {  // uniform; one-column image: the x+1 tap is the mirrored (same) element, weight 0
+        r0.a = r0.b = ld_off<float>(img, t.off0);
+        r1.a = r1.b = ld_off<float>(img, t.off0 + g.rowstep);
+    } else {
+        r0 = ld_off<PairF>(img, t.off0);
+        r1 = ld_off<PairF>(img, t.off0 + g.rowstep);
+    }
 }
 
 __device__ __forceinline__ float lean_finish(const LeanTaps &t, PairF r0, PairF r1)
 {
-    float p00 = t.swap ? r0.b : r0.a, p01 = t.swap ? r0.a : r0.b;
-    float p10 = t.swap ? r1.b : r1.a, p11 = t.swap ? r1.a : r1.b;
-    if (t.single) {  // one-column image: the x+1 tap is the mirrored (same) element, weight 0
-        p01 = p00;
-        p11 = p10;
-    }
     double acc = 0.0, c;
-    c = (double)p00; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
-    c = (double)p01; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
-    c = (double)p10; c = c * t.wy1; c = c * t.wx0; acc = acc + c;
-    c = (double)p11; c = c * t.wy1; c = c * t.wx1; acc = acc + c;
+    c = (double)r0.a; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
+    c = (double)r0.b; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
+    c = (double)r1.a; c = c * t.wy1; c = c * t.wx0; acc = acc + c;
+    c = (double)r1.b; c = c * t.wy1; c = c * t.wx1; acc = acc + c;
     return t.inside ? (float)acc : 0.0f;
 }
 
@@ -203,6 +251,8 @@ __device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float 
 enum { MODE_SINGLE = 0, MODE_ITER = 1, MODE_GRADS = 2 };
 
 
+constexpr int kMaxSegs = 40;
+
 struct LkArgs {
     const float *prev;  // [B][H][W]   (MODE_GRADS: Ix)
     const float *curr;  // [B][H][W]   (MODE_GRADS: Iy)
@@ -213,7 +263,11 @@ struct LkArgs {
     const int *sel;     // ITER: per pair, which of fu[]/fv[] holds the current flow
     const int *done;    // ITER: per pair, level already converged -> skip
     int H, W;
-    int B;              // frame pairs in the launch (k_lk5 decodes pair/tile from a 1-D grid)
+    int B;              // frame pairs in the launch (k_lkw decodes pair/tile from a 1-D grid)
+    // vertical chaining: tile rows [seg_row[s], seg_row[s+1]) form segment s, walked by one
+    // block; nseg = 0 means one tile per block (plain XCD tile order)
+    int nseg;
+    unsigned short seg_row[kMaxSegs + 1];
 };
 
 // ---------------------------------------------------------------------------
@@ -240,8 +294,11 @@ struct LkArgs {
 #ifndef OFLK_NY
 #define OFLK_NY 3
 #endif
+#ifndef OFLK_NOCHAIN
+#define OFLK_NOCHAIN 0
+#endif
 #ifndef OFLK_BATCH
-#define OFLK_BATCH 6
+#define OFLK_BATCH 4
 #endif
 // XCD-aware tile order (speed only, never correctness).  Workgroups of a 1-D grid are
 // dealt round-robin over the 8 XCDs (ids i and i+8 share an XCD, each with its own L2).
@@ -385,6 +442,34 @@ template <int HW> struct LkGeom {
     static constexpr int AS = 4 * GW;                  // staging columns (72 or 80)
 };
 
+// Levels narrower or shorter than the window: no pixel has a full window, the reference's
+// loop (lucas_kanade_core.py:101-108) runs over nothing and d = 0 everywhere.  Launched in
+// place of k_lkw so that the tile kernel may assume H, W > 2*HW (in particular W >= 2).
+// grid: (ceil(H*W / 256), B)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lk_degenerate(LkArgs a, int ntiles)
+{
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)a.H * (size_t)a.W;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int sel = 0;
+    if (MODE == MODE_ITER) {
+        if (a.done[b]) return;
+        sel = a.sel[b];
+        // |d| sums of every tile slot the finalize kernel adds up
+        if (e < (size_t)ntiles * 2) a.partial[(size_t)b * ntiles * 2 + e] = 0.0;
+    }
+    if (e >= plane) return;
+    const size_t i = (size_t)b * plane + e;
+    if (MODE == MODE_ITER) {
+        a.fu[1 - sel][i] = a.fu[sel][i] + 0.0f;   // flow += d
+        a.fv[1 - sel][i] = a.fv[sel][i] + 0.0f;
+    } else {
+        a.fu[0][i] = 0.0f;
+        a.fv[0][i] = 0.0f;
+    }
+}
+
 template <int HW, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
 {
@@ -398,23 +483,49 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     constexpr int NGRP = AH * k5GW;                        // groups of 4 staging cells
     constexpr int NV = (NGRP + 255) / 256;                 // groups per thread
     constexpr int GC = SX - HW;                            // staging column of gradient column 0
+    constexpr int NCARRY = 2 * R * AS;                     // staging cells shared with the tile below
+    constexpr int NC = (NCARRY + 255) / 256;               // carried cells per thread
 
     // one LDS block: [PA float2 | PB float2 | PC float]; avg and It alias its start
     __shared__ __attribute__((aligned(16))) float s_mem[PH * PW * 5];
+    __shared__ double s_red[2][4];
     float2 *s_pa = reinterpret_cast<float2 *>(s_mem);
     float2 *s_pb = reinterpret_cast<float2 *>(s_mem + PH * PW * 2);
     float *s_pc = s_mem + PH * PW * 4;
-    float *s_avg = s_mem;              // AH*AS = 2736 floats
-    float *s_it = s_mem + AH * AS;     // another 2736 floats
+    float *s_avg = s_mem;              // AH*AS floats
+    float *s_it = s_mem + AH * AS;     // another AH*AS floats
     static_assert(2 * AH * AS <= PH * PW * 5, "staging tiles must fit the product planes");
 
+    // A block walks a segment of vertically adjacent tiles of one 64-column strip.  The 2R staging
+    // rows (frame average, It) that a tile shares with the tile below it are carried over in
+    // registers instead of being recomputed: the exact fp64 warp, the dominant cost, runs on
+    // 24 new rows per tile instead of 30.
     const int H = a.H, W = a.W;
     const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
-    const int tiles_per_pair = tiles_x * tiles_y;
-    const int tile = xcd_tile_index(blockIdx.x, tiles_per_pair * a.B);
-    const int b = tile / tiles_per_pair;
-    const int tile_in_pair = tile - b * tiles_per_pair;
-    const int tile_y = tile_in_pair / tiles_x, tile_x = tile_in_pair - tile_y * tiles_x;
+    int b, tile_x, tile_y_first, ntile;
+    if (a.nseg == 0) {
+        const int tile = xcd_tile_index(blockIdx.x, tiles_x * tiles_y * a.B);
+        b = tile / (tiles_x * tiles_y);
+        const int t = tile - b * (tiles_x * tiles_y);
+        tile_y_first = t / tiles_x;
+        tile_x = t - tile_y_first * tiles_x;
+        ntile = 1;
+    } else {
+        // XCD x (block ids x, x+8, ...) owns the column strips [x*S/8, (x+1)*S/8) and runs
+        // their segments longest first (seg_row is built that way), so the blocks still in
+        // flight when the grid drains are the short ones
+        const int S = a.B * tiles_x;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int s_lo = (int)((long)xcd * S / 8), n = (int)((long)(xcd + 1) * S / 8) - s_lo;
+        if (n == 0) return;
+        const int seg = j / n;
+        if (seg >= a.nseg) return;
+        const int strip = s_lo + (j - seg * n);
+        b = strip / tiles_x;
+        tile_x = strip - b * tiles_x;
+        tile_y_first = a.seg_row[seg];
+        ntile = a.seg_row[seg + 1] - tile_y_first;
+    }
     int sel = 0;
     if (MODE == MODE_ITER) {
         if (a.done[b]) return;
@@ -423,331 +534,356 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     const size_t plane = (size_t)H * (size_t)W;
     const float *__restrict__ prev = a.prev + (size_t)b * plane;
     const float *__restrict__ curr = a.curr + (size_t)b * plane;
-    const int x0 = tile_x * k5TX, y0 = tile_y * k5TY;
-    const int tid = threadIdx.x;
+    const int x0 = tile_x * k5TX;
+    float carry_a[NC], carry_i[NC];
 
-    float gix[NG], giy[NG], git[NG];
-    if (MODE == MODE_GRADS) {
-        const float *__restrict__ gtp = a.aux + (size_t)b * plane;
+    for (int it = 0; it < ntile; it++) {
+        // re-derived per tile behind an opaque move: otherwise every per-thread address of all
+        // three stages is hoisted out of the loop and held in registers (occupancy 4 -> 2)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int tile_y = tile_y_first + it;
+        const int y0 = tile_y * k5TY;
+        const int tile = (b * tiles_y + tile_y) * tiles_x + tile_x;   // slot of this tile's |d| sums
+        const int rstart = (it == 0 || MODE == MODE_GRADS || OFLK_NOCHAIN) ? 0 : 2 * R;  // first staging row to compute
+
+        float gix[NG], giy[NG], git[NG];
+        if (MODE == MODE_GRADS) {
+            const float *__restrict__ gtp = a.aux + (size_t)b * plane;
 #pragma unroll
-        for (int k = 0; k < NG; k++) {
-            int e = tid + k * 256;
-            int r = e / PW, c = e - r * PW;
-            int gy = y0 - HW + r, gx = x0 - HW + c;
-            bool in = e < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            int i = in ? gy * W + gx : 0;
-            gix[k] = in ? prev[i] : 0.0f;
-            giy[k] = in ? curr[i] : 0.0f;
-            git[k] = in ? gtp[i] : 0.0f;
-        }
-    } else {
-        // ---- stage 1: second frame (warped if ITER), frame average, It -------
-        const float *__restrict__ fu_in = nullptr;
-        const float *__restrict__ fv_in = nullptr;
-        if (MODE == MODE_ITER) {
-            fu_in = a.fu[sel] + (size_t)b * plane;
-            fv_in = a.fv[sel] + (size_t)b * plane;
-        }
-        if (MODE == MODE_ITER) {
-            // Per-cell path (adjacent lanes = adjacent cells, so the bilinear gathers of a
-            // wave touch 2-3 cache lines per instruction).  All coalesced loads of the
-            // thread's NE cells go out first, then the gathers in batches of BATCH cells.
-            // Cell k of a thread is e = tid + 256 k; (row, col) advance by (3, 46) with carry
-            // at 70 columns, which avoids a division per cell.
-            constexpr int AW = k5TX + 2 * R;                 // cells per row (x0-R ..)
-            constexpr int NE = (AH * AW + 255) / 256;        // cells per thread
-            constexpr int BATCH = OFLK_BATCH;
-            constexpr int QS = 256 / AW, RS = 256 % AW;      // row / column advance per 256 cells
-            constexpr int SC = SX - R;                       // staging column of cell column 0
-            const int r0 = tid / AW, c0 = tid - r0 * AW;
-            const int Hm1 = H - 1, Wm1 = W - 1;
-            float p[NE], q[NE], uu[NE], vv[NE];
-            {
-                int r = r0, c = c0;
-#pragma unroll
-                for (int k = 0; k < NE; k++) {
-                    int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);  // "symm" ring; farther cells are never used
-                    int gx = clamp0(x0 - R + c, Wm1);
-                    unsigned i = (unsigned)(gy * W + gx);
-                    p[k] = prev[i];
-                    uu[k] = fu_in[i];
-                    vv[k] = fv_in[i];
-                    c += RS; r += QS;
-                    if (c >= AW) { c -= AW; r += 1; }
-                }
-            }
-            {
-                int r = r0, c = c0;
-#pragma unroll
-                for (int k0 = 0; k0 < NE; k0 += BATCH) {
-                    LeanTaps tp[BATCH];
-                    PairF pr0[BATCH], pr1[BATCH];
-#pragma unroll
-                    for (int j = 0; j < BATCH; j++) {
-                        if (k0 + j < NE) {
-                            int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);
-                            int gx = clamp0(x0 - R + c, Wm1);
-                            tp[j] = lean_taps(H, W, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
-                            // two 8-byte gathers per cell (the x pair of each tap row)
-                            pr0[j] = *reinterpret_cast<const PairF *>(curr + tp[j].row0);
-                            pr1[j] = *reinterpret_cast<const PairF *>(curr + tp[j].row1);
-                            c += RS; r += QS;
-                            if (c >= AW) { c -= AW; r += 1; }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < BATCH; j++)
-                        if (k0 + j < NE) q[k0 + j] = lean_finish(tp[j], pr0[j], pr1[j]);
-                }
-            }
-            {
-                int r = r0, c = c0;
-#pragma unroll
-                for (int k = 0; k < NE; k++) {
-                    if (r < AH) {
-                        float sum = p[k] + q[k];
-                        s_avg[r * AS + c + SC] = sum * 0.5f;
-                        s_it[r * AS + c + SC] = p[k] - q[k];
-                    }
-                    c += RS; r += QS;
-                    if (c >= AW) { c -= AW; r += 1; }
-                }
+            for (int k = 0; k < NG; k++) {
+                int e = tid + k * 256;
+                int r = e / PW, c = e - r * PW;
+                int gy = y0 - HW + r, gx = x0 - HW + c;
+                bool in = e < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                int i = in ? gy * W + gx : 0;
+                gix[k] = in ? prev[i] : 0.0f;
+                giy[k] = in ? curr[i] : 0.0f;
+                git[k] = in ? gtp[i] : 0.0f;
             }
         } else {
-            // clamped image coordinates of group g's first cell; `whole` = the group is one
-            // aligned float4 inside the image
-            auto group_pos = [&](int g, int &gy, int &gx, bool &whole) {
-                g = min(g, NGRP - 1);
-                int r = g / k5GW, c4 = g - r * k5GW;
-                gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
-                gx = x0 - SX + 4 * c4;
-                whole = VEC && gx >= 0 && gx + 3 < W;
-            };
-            auto load4 = [&](const float *__restrict__ src, int gy, int gx, bool whole) -> float4 {
-                if (whole) return *reinterpret_cast<const float4 *>(src + (unsigned)(gy * W + gx));
-                const float *row = src + (unsigned)(gy * W);
-                float4 r;
-                r.x = row[min(max(gx, 0), W - 1)];
-                r.y = row[min(max(gx + 1, 0), W - 1)];
-                r.z = row[min(max(gx + 2, 0), W - 1)];
-                r.w = row[min(max(gx + 3, 0), W - 1)];
-                return r;
-            };
-            // every coalesced load of the thread's NV groups goes out first (one HBM latency
-            // per tile), then, in ITER mode, 16 bilinear gathers per group
-            float4 p4[NV], q4[NV], u4[NV], v4[NV];
-    #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                int gy, gx;
-                bool whole;
-                group_pos(tid + k * 256, gy, gx, whole);
-                p4[k] = load4(prev, gy, gx, whole);
-                if (MODE == MODE_ITER) {
-                    u4[k] = load4(fu_in, gy, gx, whole);
-                    v4[k] = load4(fv_in, gy, gx, whole);
-                } else {
-                    q4[k] = load4(curr, gy, gx, whole);
+            // ---- stage 1: second frame (warped if ITER), frame average, It -------
+            if (it > 0) {
+                // rows 0 .. 2R-1 are the previous tile's rows TY .. AH-1
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    int qi = tid + j * 256;
+                    if (qi < NCARRY) {
+                        s_avg[qi] = carry_a[j];
+                        s_it[qi] = carry_i[j];
+                    }
                 }
             }
-    #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                const int g = tid + k * 256;
+            // stage-1 body, instantiated for a fresh tile (rows 0 ..) and a continuing one (rows 2R ..):
+            // with the row range known at compile time the per-thread cell count is static
+            auto stage1 = [&](auto rs) {
+                constexpr int rstart = decltype(rs)::value;
                 if (MODE == MODE_ITER) {
-                    int gy, gx;
-                    bool whole;
-                    group_pos(g, gy, gx, whole);
-                    const float uu[4] = {u4[k].x, u4[k].y, u4[k].z, u4[k].w};
-                    const float vv[4] = {v4[k].x, v4[k].y, v4[k].z, v4[k].w};
-                    BilinearTaps tp[4];
-                    float t00[4], t01[4], t10[4], t11[4], qq[4];
+                    const float *__restrict__ fu_in = a.fu[sel] + (size_t)b * plane;
+                    const float *__restrict__ fv_in = a.fv[sel] + (size_t)b * plane;
+                    // Per-cell path (adjacent lanes = adjacent cells, so the bilinear gathers of a
+                    // wave touch 2-3 cache lines per instruction).  All coalesced loads of the
+                    // thread's cells go out first, then the gathers in batches of BATCH cells.
+                    // Cell k of a thread is e = tid + 256 k over rows rstart .. AH-1; (row, col)
+                    // advance by (QS, RS) with carry at AW columns, which avoids a division per cell.
+                    constexpr int AW = k5TX + 2 * R;                 // cells per row (x0-R ..)
+                    constexpr int NE = (AH * AW + 255) / 256;        // cells per thread (full tile)
+                    constexpr int BATCH = OFLK_BATCH;
+                    constexpr int QS = 256 / AW, RS = 256 % AW;      // row / column advance per 256 cells
+                    constexpr int SC = SX - R;                       // staging column of cell column 0
+                    constexpr int ncells = (AH - rstart) * AW;
+                    const int r0 = rstart + tid / AW, c0 = tid % AW;
+                    const int Hm1 = H - 1, Wm1 = W - 1;
+                    const LeanGeom lg = lean_geom(H, W);
+                    float p[NE], q[NE], uu[NE], vv[NE];
+                    {
+                        int r = r0, c = c0;
     #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        int cx = min(max(gx + j, 0), W - 1);
-                        double xs = (double)cx + (double)uu[j];  // lucas_kanade_pyramidal.py:88-89
-                        double ys = (double)gy + (double)vv[j];
-                        tp[j] = bilinear_taps(H, W, ys, xs);
-                        t00[j] = curr[(unsigned)tp[j].i00];
-                        t01[j] = curr[(unsigned)tp[j].i01];
-                        t10[j] = curr[(unsigned)tp[j].i10];
-                        t11[j] = curr[(unsigned)tp[j].i11];
+                        for (int k = 0; k < NE; k++) {
+                            if (k * 256 < ncells) {  // uniform: cell k exists for some thread
+                                int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);  // "symm" ring; farther cells are never used
+                                int gx = clamp0(x0 - R + c, Wm1);
+                                unsigned i = ((unsigned)__mul24(gy, W) + (unsigned)gx) * 4u;
+                                p[k] = ld_off<float>(prev, i);
+                                uu[k] = ld_off<float>(fu_in, i);
+                                vv[k] = ld_off<float>(fv_in, i);
+                                c += RS; r += QS;
+                                if (c >= AW) { c -= AW; r += 1; }
+                            }
+                        }
+                    }
+                    {
+                        int r = r0, c = c0;
+    #pragma unroll
+                        for (int k0 = 0; k0 < NE; k0 += BATCH) {
+                            if (k0 * 256 < ncells) {
+                                LeanTaps tp[BATCH];
+                                PairF pr0[BATCH], pr1[BATCH];
+    #pragma unroll
+                                for (int j = 0; j < BATCH; j++) {
+                                    if (k0 + j < NE && (k0 + j) * 256 < ncells) {
+                                        int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);
+                                        int gx = clamp0(x0 - R + c, Wm1);
+                                        tp[j] = lean_taps(lg, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
+                                        // two 8-byte gathers per cell (the x pair of each tap row)
+                                        lean_load<false>(lg, curr, tp[j], pr0[j], pr1[j]);
+                                        c += RS; r += QS;
+                                        if (c >= AW) { c -= AW; r += 1; }
+                                    }
+                                }
+    #pragma unroll
+                                for (int j = 0; j < BATCH; j++)
+                                    if (k0 + j < NE && (k0 + j) * 256 < ncells) {
+                                        q[k0 + j] = lean_finish(tp[j], pr0[j], pr1[j]);
+                                        pin(q[k0 + j]);  // finished here, not sunk to its use after the last batch
+                                    }
+                                __builtin_amdgcn_sched_barrier(0);  // one batch of taps in flight at a time
+                            }
+                        }
+                    }
+                    {
+                        int r = r0, c = c0;
+    #pragma unroll
+                        for (int k = 0; k < NE; k++) {
+                            if (k * 256 < ncells) {
+                                if (r < AH) {
+                                    float sum = p[k] + q[k];
+                                    s_avg[r * AS + c + SC] = sum * 0.5f;
+                                    s_it[r * AS + c + SC] = p[k] - q[k];
+                                }
+                                c += RS; r += QS;
+                                if (c >= AW) { c -= AW; r += 1; }
+                            }
+                        }
+                    }
+                } else {
+                    // SINGLE: groups of four cells over staging rows rstart .. AH-1
+                    constexpr int ngroups = (AH - rstart) * k5GW;
+                    // clamped image coordinates of group g's first cell; `whole` = the group is one
+                    // aligned float4 inside the image
+                    auto group_pos = [&](int g, int &gy, int &gx, bool &whole) {
+                        g = min(g, ngroups - 1);
+                        int r = rstart + g / k5GW, c4 = g % k5GW;
+                        gy = min(max(y0 - R + r, 0), H - 1);  // "symm" ring; farther cells are never used
+                        gx = x0 - SX + 4 * c4;
+                        whole = VEC && gx >= 0 && gx + 3 < W;
+                    };
+                    auto load4 = [&](const float *__restrict__ src, int gy, int gx, bool whole) -> float4 {
+                        if (whole) return *reinterpret_cast<const float4 *>(src + (unsigned)(gy * W + gx));
+                        const float *row = src + (unsigned)(gy * W);
+                        float4 r;
+                        r.x = row[min(max(gx, 0), W - 1)];
+                        r.y = row[min(max(gx + 1, 0), W - 1)];
+                        r.z = row[min(max(gx + 2, 0), W - 1)];
+                        r.w = row[min(max(gx + 3, 0), W - 1)];
+                        return r;
+                    };
+                    // every coalesced load of the thread's groups goes out first (one HBM latency per tile)
+                    float4 p4[NV], q4[NV];
+    #pragma unroll
+                    for (int k = 0; k < NV; k++) {
+                        if (k * 256 < ngroups) {
+                            int gy, gx;
+                            bool whole;
+                            group_pos(tid + k * 256, gy, gx, whole);
+                            p4[k] = load4(prev, gy, gx, whole);
+                            q4[k] = load4(curr, gy, gx, whole);
+                        }
                     }
     #pragma unroll
-                    for (int j = 0; j < 4; j++) qq[j] = bilinear_finish(tp[j], t00[j], t01[j], t10[j], t11[j]);
-                    q4[k] = make_float4(qq[0], qq[1], qq[2], qq[3]);
+                    for (int k = 0; k < NV; k++) {
+                        const int g = tid + k * 256;
+                        if (k * 256 < ngroups && g < ngroups) {
+                            float4 pp = p4[k], qv = q4[k], av, dv;
+                            // (prev + curr) / 2.0 and prev - curr, lucas_kanade_core.py:36, :43
+                            av.x = (pp.x + qv.x) * 0.5f; av.y = (pp.y + qv.y) * 0.5f;
+                            av.z = (pp.z + qv.z) * 0.5f; av.w = (pp.w + qv.w) * 0.5f;
+                            dv.x = pp.x - qv.x; dv.y = pp.y - qv.y; dv.z = pp.z - qv.z; dv.w = pp.w - qv.w;
+                            const int o = rstart * AS + 4 * g;  // = r*AS + 4*c4
+                            *reinterpret_cast<float4 *>(&s_avg[o]) = av;
+                            *reinterpret_cast<float4 *>(&s_it[o]) = dv;
+                        }
+                    }
                 }
-                if (g < NGRP) {
-                    float4 pp = p4[k], qv = q4[k], av, dv;
-                    // (prev + curr) / 2.0 and prev - curr, lucas_kanade_core.py:36, :43
-                    av.x = (pp.x + qv.x) * 0.5f; av.y = (pp.y + qv.y) * 0.5f;
-                    av.z = (pp.z + qv.z) * 0.5f; av.w = (pp.w + qv.w) * 0.5f;
-                    dv.x = pp.x - qv.x; dv.y = pp.y - qv.y; dv.z = pp.z - qv.z; dv.w = pp.w - qv.w;
-                    *reinterpret_cast<float4 *>(&s_avg[4 * g]) = av;  // 4*g = r*AS + 4*c4
-                    *reinterpret_cast<float4 *>(&s_it[4 * g]) = dv;
+            };
+            if (rstart == 0) stage1(std::integral_constant<int, 0>{});
+            else stage1(std::integral_constant<int, 2 * R>{});
+            __syncthreads();
+            // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                int e = tid + k * 256;
+                if (e >= PH * PW) e = PH * PW - 1;  // tail threads recompute the last cell
+                int r = e / PW, c = e - r * PW;
+                // gradient cell (r, c) = image (y0-HW+r, x0-HW+c) = staging cell (r+1, c+GC)
+                const float *ap = &s_avg[(r + 1) * AS + (c + GC)];
+                float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
+                float a_0m = ap[-1], a_0p = ap[1];
+                float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
+                float ix = a_pp * -0.125f;
+                ix = fmaf(a_pm, 0.125f, ix);
+                ix = fmaf(a_0p, -0.25f, ix);
+                ix = fmaf(a_0m, 0.25f, ix);
+                ix = fmaf(a_mp, -0.125f, ix);
+                ix = fmaf(a_mm, 0.125f, ix);
+                float iy = a_pp * -0.125f;
+                iy = fmaf(a_p0, -0.25f, iy);
+                iy = fmaf(a_pm, -0.125f, iy);
+                iy = fmaf(a_mp, 0.125f, iy);
+                iy = fmaf(a_m0, 0.25f, iy);
+                iy = fmaf(a_mm, 0.125f, iy);
+                gix[k] = ix;
+                giy[k] = iy;
+                git[k] = s_it[(r + 1) * AS + (c + GC)];
+            }
+            if (it + 1 < ntile) {
+                // staging rows TY .. AH-1 are the next tile's rows 0 .. 2R-1
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    int qi = tid + j * 256;
+                    if (qi < NCARRY) {
+                        carry_a[j] = s_avg[k5TY * AS + qi];
+                        carry_i[j] = s_it[k5TY * AS + qi];
+                    }
                 }
             }
+            __syncthreads();  // everyone is done reading avg / It: the planes may overwrite them
         }
-        __syncthreads();
-        // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
+        // ---- products into the interleaved planes --------------------------------
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             int e = tid + k * 256;
-            if (e >= PH * PW) e = PH * PW - 1;  // tail threads recompute the last cell
-            int r = e / PW, c = e - r * PW;
-            // gradient cell (r, c) = image (y0-HW+r, x0-HW+c) = staging cell (r+1, c+GC)
-            const float *ap = &s_avg[(r + 1) * AS + (c + GC)];
-            float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
-            float a_0m = ap[-1], a_0p = ap[1];
-            float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
-            float ix = a_pp * -0.125f;
-            ix = fmaf(a_pm, 0.125f, ix);
-            ix = fmaf(a_0p, -0.25f, ix);
-            ix = fmaf(a_0m, 0.25f, ix);
-            ix = fmaf(a_mp, -0.125f, ix);
-            ix = fmaf(a_mm, 0.125f, ix);
-            float iy = a_pp * -0.125f;
-            iy = fmaf(a_p0, -0.25f, iy);
-            iy = fmaf(a_pm, -0.125f, iy);
-            iy = fmaf(a_mp, 0.125f, iy);
-            iy = fmaf(a_m0, 0.25f, iy);
-            iy = fmaf(a_mm, 0.125f, iy);
-            gix[k] = ix;
-            giy[k] = iy;
-            git[k] = s_it[(r + 1) * AS + (c + GC)];
-        }
-        __syncthreads();  // everyone is done reading avg / It: the planes may overwrite them
-    }
-    // ---- products into the interleaved planes --------------------------------
-#pragma unroll
-    for (int k = 0; k < NG; k++) {
-        int e = tid + k * 256;
-        if (e < PH * PW) {
-            float ix = gix[k], iy = giy[k], it = git[k];
-            s_pa[e] = make_float2(ix * ix, iy * iy);
-            s_pb[e] = make_float2(ix * iy, ix * it);
-            s_pc[e] = iy * it;
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 3: shared-r window sums (pk over plane pairs), solve, write -----
-    // thread = 2 (x) by 4 (y) outputs; a half-wave spans one tile row, so the
-    // 16-byte LDS reads of 32 adjacent lanes are contiguous (conflict-free)
-    constexpr int NY = k5NY;
-    constexpr int RW = 2 + 2 * HW;   // product columns a thread reads per row
-    const int tx = tid & 31, ty = tid >> 5;
-    float2 sA[NY][2], sB[NY][2];
-    float sC[NY][2];
-    // rows of the interleaved planes: RW float2 = RW/2 aligned 16-byte reads; RW floats = RW/2 8-byte reads
-    auto load_f2 = [](const float2 *src, float2 (&row)[RW]) {
-        const float4 *r4 = reinterpret_cast<const float4 *>(src);
-#pragma unroll
-        for (int j = 0; j < RW / 2; j++) {
-            float4 q = r4[j];
-            row[2 * j] = make_float2(q.x, q.y);
-            row[2 * j + 1] = make_float2(q.z, q.w);
-        }
-    };
-    auto load_f1 = [](const float *src, float (&row)[RW]) {
-        const float2 *r2 = reinterpret_cast<const float2 *>(src);
-#pragma unroll
-        for (int j = 0; j < RW / 2; j++) {
-            float2 q = r2[j];
-            row[2 * j] = q.x;
-            row[2 * j + 1] = q.y;
-        }
-    };
-    if constexpr (HW == 2) {
-        const float2 *ba = &s_pa[(NY * ty) * PW + 2 * tx];
-        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(ba + i * PW, row); }, sA);
-        const float2 *bb = &s_pb[(NY * ty) * PW + 2 * tx];
-        patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
-        const float *bc = &s_pc[(NY * ty) * PW + 2 * tx];
-        patch5_sums<float, NY>([&](int i, float (&row)[6]) { load_f1(bc + i * PW, row); }, sC);
-    } else {
-#pragma unroll
-        for (int oy = 0; oy < NY; oy++) {
-            const float2 *ba = &s_pa[(NY * ty + oy) * PW + 2 * tx];
-            window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(ba + i * PW, row); }, sA[oy]);
-            __builtin_amdgcn_sched_barrier(0);
-            const float2 *bb = &s_pb[(NY * ty + oy) * PW + 2 * tx];
-            window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(bb + i * PW, row); }, sB[oy]);
-            __builtin_amdgcn_sched_barrier(0);
-            const float *bc = &s_pc[(NY * ty + oy) * PW + 2 * tx];
-            window_sums_row<float, HW, 2>([&](int i, float (&row)[RW]) { load_f1(bc + i * PW, row); }, sC[oy]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    const int gxb = x0 + 2 * tx;
-    double su = 0.0, sv = 0.0;
-    float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
-    float *__restrict__ ov = a.fv[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
-    const float *__restrict__ iu = MODE == MODE_ITER ? a.fu[sel] + (size_t)b * plane : nullptr;
-    const float *__restrict__ iv = MODE == MODE_ITER ? a.fv[sel] + (size_t)b * plane : nullptr;
-#pragma unroll
-    for (int oy = 0; oy < NY; oy++) {
-        const int gy = y0 + NY * ty + oy;
-        float du[2], dv[2];
-#pragma unroll
-        for (int o = 0; o < 2; o++) {
-            float u, v;
-            lk_solve(sA[oy][o].x, sA[oy][o].y, sB[oy][o].x, sB[oy][o].y, sC[oy][o], u, v);
-            int gx = gxb + o;
-            bool interior = gy >= HW && gy < H - HW && gx >= HW && gx < W - HW;
-            du[o] = interior ? u : 0.0f;
-            dv[o] = interior ? v : 0.0f;
-            if (MODE == MODE_ITER && gy < H && gx < W) {
-                su += (double)fabsf(du[o]);
-                sv += (double)fabsf(dv[o]);
+            if (e < PH * PW) {
+                float ix = gix[k], iy = giy[k], itv = git[k];
+                s_pa[e] = make_float2(ix * ix, iy * iy);
+                s_pb[e] = make_float2(ix * iy, ix * itv);
+                s_pc[e] = iy * itv;
             }
         }
-        if (gy < H && gxb < W) {
-            int i = gy * W + gxb;
-            if (((W & 1) == 0) && gxb + 1 < W) {
-                float2 ru = make_float2(du[0], du[1]);
-                float2 rv = make_float2(dv[0], dv[1]);
-                if (MODE == MODE_ITER) {
-                    // flow += d (lucas_kanade_pyramidal.py:209-210)
-                    float2 pu = *reinterpret_cast<const float2 *>(iu + i);
-                    float2 pv = *reinterpret_cast<const float2 *>(iv + i);
-                    ru.x = pu.x + ru.x; ru.y = pu.y + ru.y;
-                    rv.x = pv.x + rv.x; rv.y = pv.y + rv.y;
-                }
-                *reinterpret_cast<float2 *>(ou + i) = ru;
-                *reinterpret_cast<float2 *>(ov + i) = rv;
-            } else {
+        __syncthreads();
+
+        // ---- stage 3: window sums in NumPy order (pk over plane pairs), solve, write -----
+        // thread = 2 (x) by NY (y) outputs; a half-wave spans one tile row, so the
+        // 16-byte LDS reads of 32 adjacent lanes are contiguous (conflict-free)
+        constexpr int NY = k5NY;
+        constexpr int RW = 2 + 2 * HW;   // product columns a thread reads per row
+        const int tx = tid & 31, ty = tid >> 5;
+        float2 sA[NY][2], sB[NY][2];
+        float sC[NY][2];
+        // rows of the interleaved planes: RW float2 = RW/2 aligned 16-byte reads; RW floats = RW/2 8-byte reads
+        auto load_f2 = [](const float2 *src, float2 (&row)[RW]) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(src);
 #pragma unroll
-                for (int o = 0; o < 2; o++) {
-                    if (gxb + o < W) {
-                        float ru = du[o], rv = dv[o];
-                        if (MODE == MODE_ITER) {
-                            ru = iu[i + o] + ru;
-                            rv = iv[i + o] + rv;
+            for (int j = 0; j < RW / 2; j++) {
+                float4 qv = r4[j];
+                row[2 * j] = make_float2(qv.x, qv.y);
+                row[2 * j + 1] = make_float2(qv.z, qv.w);
+            }
+        };
+        auto load_f1 = [](const float *src, float (&row)[RW]) {
+            const float2 *r2 = reinterpret_cast<const float2 *>(src);
+#pragma unroll
+            for (int j = 0; j < RW / 2; j++) {
+                float2 qv = r2[j];
+                row[2 * j] = qv.x;
+                row[2 * j + 1] = qv.y;
+            }
+        };
+        if constexpr (HW == 2) {
+            const float2 *ba = &s_pa[(NY * ty) * PW + 2 * tx];
+            patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(ba + i * PW, row); }, sA);
+            const float2 *bb = &s_pb[(NY * ty) * PW + 2 * tx];
+            patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
+            const float *bc = &s_pc[(NY * ty) * PW + 2 * tx];
+            patch5_sums<float, NY>([&](int i, float (&row)[6]) { load_f1(bc + i * PW, row); }, sC);
+        } else {
+#pragma unroll
+            for (int oy = 0; oy < NY; oy++) {
+                const float2 *ba = &s_pa[(NY * ty + oy) * PW + 2 * tx];
+                window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(ba + i * PW, row); }, sA[oy]);
+                __builtin_amdgcn_sched_barrier(0);
+                const float2 *bb = &s_pb[(NY * ty + oy) * PW + 2 * tx];
+                window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(bb + i * PW, row); }, sB[oy]);
+                __builtin_amdgcn_sched_barrier(0);
+                const float *bc = &s_pc[(NY * ty + oy) * PW + 2 * tx];
+                window_sums_row<float, HW, 2>([&](int i, float (&row)[RW]) { load_f1(bc + i * PW, row); }, sC[oy]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        const int gxb = x0 + 2 * tx;
+        double su = 0.0, sv = 0.0;
+        float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
+        float *__restrict__ ov = a.fv[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
+        const float *__restrict__ iu = MODE == MODE_ITER ? a.fu[sel] + (size_t)b * plane : nullptr;
+        const float *__restrict__ iv = MODE == MODE_ITER ? a.fv[sel] + (size_t)b * plane : nullptr;
+#pragma unroll
+        for (int oy = 0; oy < NY; oy++) {
+            const int gy = y0 + NY * ty + oy;
+            float du[2], dv[2];
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                float u, v;
+                lk_solve(sA[oy][o].x, sA[oy][o].y, sB[oy][o].x, sB[oy][o].y, sC[oy][o], u, v);
+                int gx = gxb + o;
+                // borders stay zero (lucas_kanade_core.py:101-108)
+                bool interior = gy >= HW && gy < H - HW && gx >= HW && gx < W - HW;
+                du[o] = interior ? u : 0.0f;
+                dv[o] = interior ? v : 0.0f;
+                if (MODE == MODE_ITER && gy < H && gx < W) {
+                    su += (double)fabsf(du[o]);
+                    sv += (double)fabsf(dv[o]);
+                }
+            }
+            if (gy < H && gxb < W) {
+                int i = gy * W + gxb;
+                if (((W & 1) == 0) && gxb + 1 < W) {
+                    float2 ru = make_float2(du[0], du[1]);
+                    float2 rv = make_float2(dv[0], dv[1]);
+                    if (MODE == MODE_ITER) {
+                        // flow += d (lucas_kanade_pyramidal.py:209-210)
+                        float2 pu = *reinterpret_cast<const float2 *>(iu + i);
+                        float2 pv = *reinterpret_cast<const float2 *>(iv + i);
+                        ru.x = pu.x + ru.x; ru.y = pu.y + ru.y;
+                        rv.x = pv.x + rv.x; rv.y = pv.y + rv.y;
+                    }
+                    *reinterpret_cast<float2 *>(ou + i) = ru;
+                    *reinterpret_cast<float2 *>(ov + i) = rv;
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 2; o++) {
+                        if (gxb + o < W) {
+                            float ru = du[o], rv = dv[o];
+                            if (MODE == MODE_ITER) {
+                                ru = iu[i + o] + ru;
+                                rv = iv[i + o] + rv;
+                            }
+                            ou[i + o] = ru;
+                            ov[i + o] = rv;
                         }
-                        ou[i + o] = ru;
-                        ov[i + o] = rv;
                     }
                 }
             }
         }
-    }
 
-    if (MODE == MODE_ITER) {
-        __shared__ double s_red[2][4];
+        if (MODE == MODE_ITER) {
+            // fixed-order block reduction of the |d| sums (fp64)
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            su += __shfl_down(su, off, 64);
-            sv += __shfl_down(sv, off, 64);
+            for (int off = 32; off >= 1; off >>= 1) {
+                su += __shfl_down(su, off, 64);
+                sv += __shfl_down(sv, off, 64);
+            }
+            if ((tid & 63) == 0) {
+                s_red[0][tid >> 6] = su;
+                s_red[1][tid >> 6] = sv;
+            }
         }
-        if ((tid & 63) == 0) {
-            s_red[0][tid >> 6] = su;
-            s_red[1][tid >> 6] = sv;
-        }
-        __syncthreads();
-        if (tid == 0) {
+        // stage 3 has read the planes (the next tile's staging overwrites them) and s_red is complete
+        if (MODE == MODE_ITER || it + 1 < ntile) __syncthreads();
+        if (MODE == MODE_ITER && tid == 0) {
             double tu = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
             double tv = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
-            a.partial[(size_t)tile * 2 + 0] = tu;   // tile = b * tiles_per_pair + index in pair
+            a.partial[(size_t)tile * 2 + 0] = tu;   // slot = (b * tiles_y + tile_y) * tiles_x + tile_x
             a.partial[(size_t)tile * 2 + 1] = tv;
         }
     }
@@ -1201,9 +1337,10 @@ __global__ __launch_bounds__(256) void k_warp(const float *__restrict__ img,
     size_t i = (size_t)y * W + x;
     // same tap code as the fused iteration kernel (k_lk5), so the unit tests of
     // warp_image exercise it
-    LeanTaps t = lean_taps(H, W, y, x, fu[base + i], fv[base + i]);
-    PairF r0 = *reinterpret_cast<const PairF *>(img + base + t.row0);
-    PairF r1 = *reinterpret_cast<const PairF *>(img + base + t.row1);
+    const LeanGeom lg = lean_geom(H, W);
+    LeanTaps t = lean_taps(lg, y, x, fu[base + i], fv[base + i]);
+    PairF r0, r1;
+    lean_load<true>(lg, img + base, t, r0, r1);
     out[base + i] = lean_finish(t, r0, r1);
 }
 
