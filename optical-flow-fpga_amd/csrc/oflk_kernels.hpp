@@ -318,6 +318,23 @@ __device__ __forceinline__ int xcd_tile_index(int bid, int ntiles)
     return (r % (NXCD - 1)) * chunk + full + r / (NXCD - 1);
 }
 
+// Sum over the 64 lanes of a wave in a fixed order, result in lane 63 (other lanes hold
+// partial sums): row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15 and 31.
+__device__ __forceinline__ float wave_sum_to_lane63(float x)
+{
+    auto dpp = [](float v, auto ctrl, auto row_mask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                    decltype(row_mask)::value, 0xf, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+    x += dpp(x, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+    x += dpp(x, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+    x += dpp(x, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+    x += dpp(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 -> rows 1, 3
+    x += dpp(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 constexpr int k5NY = OFLK_NY;      // output rows per thread
 constexpr int k5TX = 64;
 constexpr int k5TY = 8 * k5NY;     // 8 thread rows x NY
@@ -812,54 +829,60 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         }
 
         const int gxb = x0 + 2 * tx;
-        double su = 0.0, sv = 0.0;
+        float su = 0.0f, sv = 0.0f;
         float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
         float *__restrict__ ov = a.fv[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
         const float *__restrict__ iu = MODE == MODE_ITER ? a.fu[sel] + (size_t)b * plane : nullptr;
         const float *__restrict__ iv = MODE == MODE_ITER ? a.fv[sel] + (size_t)b * plane : nullptr;
+        // borders stay zero (lucas_kanade_core.py:101-108); the column tests are per thread,
+        // the row test per output row
+        const bool okx0 = (gxb >= HW) & (gxb < W - HW), okx1 = (gxb + 1 >= HW) & (gxb + 1 < W - HW);
+        const int gyb = y0 + NY * ty;
+        // byte offset of the thread's first output inside the plane (a plane is < 4 GiB)
+        unsigned ofs = ((unsigned)__mul24(gyb, W) + (unsigned)gxb) * 4u;
+        const unsigned rowbytes = 4u * (unsigned)W;
+        const bool pairs = VEC || (W & 1) == 0;   // gxb is even: an aligned float2 inside the row
 #pragma unroll
-        for (int oy = 0; oy < NY; oy++) {
-            const int gy = y0 + NY * ty + oy;
+        for (int oy = 0; oy < NY; oy++, ofs += rowbytes) {
+            const int gy = gyb + oy;
+            const bool oky = (gy >= HW) & (gy < H - HW);
             float du[2], dv[2];
 #pragma unroll
             for (int o = 0; o < 2; o++) {
                 float u, v;
                 lk_solve(sA[oy][o].x, sA[oy][o].y, sB[oy][o].x, sB[oy][o].y, sC[oy][o], u, v);
-                int gx = gxb + o;
-                // borders stay zero (lucas_kanade_core.py:101-108)
-                bool interior = gy >= HW && gy < H - HW && gx >= HW && gx < W - HW;
+                const bool interior = oky & (o ? okx1 : okx0);
                 du[o] = interior ? u : 0.0f;
                 dv[o] = interior ? v : 0.0f;
-                if (MODE == MODE_ITER && gy < H && gx < W) {
-                    su += (double)fabsf(du[o]);
-                    sv += (double)fabsf(dv[o]);
+                if (MODE == MODE_ITER) {  // pixels outside the image are not interior: they add 0
+                    su += fabsf(du[o]);
+                    sv += fabsf(dv[o]);
                 }
             }
             if (gy < H && gxb < W) {
-                int i = gy * W + gxb;
-                if (((W & 1) == 0) && gxb + 1 < W) {
+                if (pairs) {
                     float2 ru = make_float2(du[0], du[1]);
                     float2 rv = make_float2(dv[0], dv[1]);
                     if (MODE == MODE_ITER) {
                         // flow += d (lucas_kanade_pyramidal.py:209-210)
-                        float2 pu = *reinterpret_cast<const float2 *>(iu + i);
-                        float2 pv = *reinterpret_cast<const float2 *>(iv + i);
+                        const float2 pu = ld_off<float2>(iu, ofs);
+                        const float2 pv = ld_off<float2>(iv, ofs);
                         ru.x = pu.x + ru.x; ru.y = pu.y + ru.y;
                         rv.x = pv.x + rv.x; rv.y = pv.y + rv.y;
                     }
-                    *reinterpret_cast<float2 *>(ou + i) = ru;
-                    *reinterpret_cast<float2 *>(ov + i) = rv;
+                    st_off<float2>(ou, ofs, ru);
+                    st_off<float2>(ov, ofs, rv);
                 } else {
 #pragma unroll
                     for (int o = 0; o < 2; o++) {
                         if (gxb + o < W) {
                             float ru = du[o], rv = dv[o];
                             if (MODE == MODE_ITER) {
-                                ru = iu[i + o] + ru;
-                                rv = iv[i + o] + rv;
+                                ru = ld_off<float>(iu, ofs + 4u * o) + ru;
+                                rv = ld_off<float>(iv, ofs + 4u * o) + rv;
                             }
-                            ou[i + o] = ru;
-                            ov[i + o] = rv;
+                            st_off<float>(ou, ofs + 4u * o, ru);
+                            st_off<float>(ov, ofs + 4u * o, rv);
                         }
                     }
                 }
@@ -867,15 +890,14 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         }
 
         if (MODE == MODE_ITER) {
-            // fixed-order block reduction of the |d| sums (fp64)
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                su += __shfl_down(su, off, 64);
-                sv += __shfl_down(sv, off, 64);
-            }
-            if ((tid & 63) == 0) {
-                s_red[0][tid >> 6] = su;
-                s_red[1][tid >> 6] = sv;
+            // |d| sums of the tile: six fp32 terms per thread, a fixed-order wave reduction
+            // (DPP adds, total in lane 63), then fp64 across the four waves.  The reference's
+            // np.mean is itself an fp32 pairwise sum; see k_finalize.
+            su = wave_sum_to_lane63(su);
+            sv = wave_sum_to_lane63(sv);
+            if ((tid & 63) == 63) {
+                s_red[0][tid >> 6] = (double)su;
+                s_red[1][tid >> 6] = (double)sv;
             }
         }
         // stage 3 has read the planes (the next tile's staging overwrites them) and s_red is complete
