@@ -153,10 +153,10 @@ int window_hw(int window_size, int *hw)
 }
 
 // ---- kernel classes for the per-kernel event timing --------------------------
-enum KClass { KC_LK_SINGLE = 0, KC_LK_ITER, KC_LK_ITER_FINEST, KC_FINALIZE, KC_BLUR, KC_RESAMPLE,
-              KC_UPSAMPLE, KC_EXPORT, KC_MEMSET, KC_PYR_FUSED, KC_COUNT };
-const char *kClassNames[KC_COUNT] = {"lk_single", "lk_iter", "lk_iter_finest", "finalize", "blur",
-                                     "pyr_resample", "flow_upsample", "export_fixup", "memset",
+enum KClass { KC_LK_SINGLE = 0, KC_LK_ITER, KC_LK_ITER_FINEST, KC_BLUR, KC_RESAMPLE,
+              KC_UPSAMPLE, KC_EXPORT, KC_INIT, KC_PYR_FUSED, KC_COUNT };
+const char *kClassNames[KC_COUNT] = {"lk_single", "lk_iter", "lk_iter_finest", "blur",
+                                     "pyr_resample", "flow_upsample", "export_fixup", "call_init",
                                      "pyr_down_fused"};
 
 }  // namespace
@@ -172,9 +172,9 @@ struct oflk_plan {
     // per level one block: [slot 0..1][u, v][B][h][w]; the finest level owns one
     // slot only (its other slot is the caller's output buffers)
     float *flow[OFLK_MAX_LEVELS] = {nullptr};
-    double *partial = nullptr;                    // [B][nblk_max][2]
-    int *state = nullptr;                         // sel[L][B], done[L][B], iters_run[B][L]
-    float *log = nullptr;                         // [B][L][K][2]
+    // per-call state, one allocation, zeroed by k_call_init at the start of every call:
+    //   acc[B][L][K][kAccShards][kAccStride] (u64) | iters_run[B][L] (i32) | log[B][L][K][2] (f32)
+    unsigned long long *state = nullptr;
     GaussW gauss;
     // profiling
     bool prof = false;
@@ -188,10 +188,14 @@ struct oflk_plan {
     size_t npix(int l) const { return (size_t)dims[2 * l] * (size_t)dims[2 * l + 1]; }
     float *fu(int l, int slot) const { return flow[l] + (size_t)(2 * slot) * B * npix(l); }
     float *fv(int l, int slot) const { return flow[l] + (size_t)(2 * slot + 1) * B * npix(l); }
-    int *sel(int l) const { return state + (size_t)l * B; }
-    int *done(int l) const { return state + (size_t)(L + l) * B; }
-    int *iters_run() const { return state + (size_t)2 * L * B; }
-    size_t state_ints() const { return (size_t)3 * L * B; }
+    int Kc() const { return std::max(K, 1); }
+    size_t n_acc() const { return (size_t)B * L * Kc() * kAccShards * kAccStride; }
+    unsigned long long *acc() const { return state; }
+    int *iters_run() const { return reinterpret_cast<int *>(state + n_acc()); }
+    float *log() const { return reinterpret_cast<float *>(iters_run() + (size_t)B * L); }
+    size_t n_log() const { return (size_t)B * L * Kc() * 2; }
+    // 32-bit words of the whole state block (rounded up to a multiple of 4)
+    size_t state_words() const { return ((2 * n_acc() + (size_t)B * L + n_log()) + 3) & ~(size_t)3; }
 };
 
 namespace {
@@ -223,6 +227,19 @@ struct Prof {
     }
 };
 
+// smallest |d| total (fixed point) whose mean reads >= float32(0.01) for a level of `count`
+// pixels: lk_mean_of is non-decreasing in the total, so "mean < 0.01" <=> total < threshold
+unsigned long long conv_threshold(double count)
+{
+    unsigned long long lo = 0, hi = 1ull << 62;   // mean(lo) < 0.01 <= mean(hi)
+    while (hi - lo > 1) {
+        const unsigned long long mid = lo + (hi - lo) / 2;
+        if (lk_mean_of(mid, count) < 0.01f) lo = mid;
+        else hi = mid;
+    }
+    return hi;
+}
+
 template <int MODE>
 int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_in, int B)
 {
@@ -236,10 +253,8 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     const int tiles_x = (a.W + k5TX - 1) / k5TX, tiles_y = (a.H + k5TY - 1) / k5TY;
     if (a.W <= 2 * hw || a.H <= 2 * hw) {
         // nothing has a full window: all-zero d (and k_lkw may assume H, W > 2*hw)
-        const int ntiles = tiles_x * tiles_y;
-        const size_t work = std::max((size_t)a.H * (size_t)a.W, (size_t)ntiles * 2);
-        hipLaunchKernelGGL((k_lk_degenerate<MODE>), dim3((unsigned)((work + 255) / 256), (unsigned)B), dim3(256), 0, s, a,
-                           ntiles);
+        const unsigned nb = (unsigned)(((size_t)a.H * (size_t)a.W + 255) / 256);
+        hipLaunchKernelGGL((k_lk_degenerate<MODE>), dim3(nb, (unsigned)B), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         return OFLK_OK;
     }
@@ -372,7 +387,7 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
     ResampleArgs r{};
     r.in[0] = tmpB;
     r.out[0] = out;
-    r.sel = nullptr;
+    r.acc = nullptr;
     r.in_sel_stride = 0;
     r.H = h; r.W = w; r.Ho = ho; r.Wo = wo;
     r.ly = make_linspace(h, ho);
@@ -410,9 +425,7 @@ void plan_free(oflk_plan *p)
     }
     if (p->tmpA) (void)hipFree(p->tmpA);
     if (p->tmpB) (void)hipFree(p->tmpB);
-    if (p->partial) (void)hipFree(p->partial);
     if (p->state) (void)hipFree(p->state);
-    if (p->log) (void)hipFree(p->log);
     for (auto &e : p->pending) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -487,19 +500,14 @@ OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, 
         rc = dmalloc(&p->tmpA, 2 * (size_t)B * N, &p->ws_bytes);
         if (!rc) rc = dmalloc(&p->tmpB, 2 * (size_t)B * N, &p->ws_bytes);
     }
-    size_t nblk_max = 1;
     for (int l = 0; l < levels && !rc; l++) {
         size_t n = (size_t)dims[2 * l] * dims[2 * l + 1];
         if (l < levels - 1) rc = dmalloc(&p->pyr[l], 2 * (size_t)B * n, &p->ws_bytes);
         // finest level: one of the ping-pong buffers is the caller's output
         int nb = (l == levels - 1) ? 1 : 2;
         if (!rc) rc = dmalloc(&p->flow[l], (size_t)nb * 2 * B * n, &p->ws_bytes);
-        size_t nblk = (size_t)((dims[2 * l + 1] + k5TX - 1) / k5TX) * ((dims[2 * l] + k5TY - 1) / k5TY);
-        nblk_max = std::max(nblk_max, nblk);
     }
-    if (!rc) rc = dmalloc(&p->partial, (size_t)B * nblk_max * 2, &p->ws_bytes);
-    if (!rc) rc = dmalloc(&p->state, p->state_ints(), &p->ws_bytes);
-    if (!rc) rc = dmalloc(&p->log, (size_t)B * levels * std::max(iters, 1) * 2, &p->ws_bytes);
+    if (!rc) rc = dmalloc(&p->state, p->state_words() / 2, &p->ws_bytes);
     if (rc) {
         std::string keep = t_err;
         plan_free(p);
@@ -556,13 +564,6 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
         }
     }
 
-    // ---- per-call state: sel = 0, done = 0, iters_run = 0, log = 0 ------------
-    {
-        Prof pr(p, s, KC_MEMSET);
-        HIP_TRY(hipMemsetAsync(p->state, 0, p->state_ints() * sizeof(int), s));
-        HIP_TRY(hipMemsetAsync(p->log, 0, (size_t)B * L * std::max(K, 1) * 2 * sizeof(float), s));
-    }
-
     // the caller's buffers are the ping-pong slot the final flow lands in when no
     // level exits early at the finest level: slot K % 2
     const int want = K & 1;
@@ -577,15 +578,19 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
     fu[L - 1][1 - want] = p->fu(L - 1, 0);
     fv[L - 1][1 - want] = p->fv(L - 1, 0);
 
+    // ---- per-call state (acc, arrived, sel, done, iters_run, log) = 0 and, in the same
+    // launch, flow = zeros at the coarsest level (:182-184) ------------------------
+    {
+        Prof pr(p, s, KC_INIT);
+        hipLaunchKernelGGL(k_call_init, dim3(256), dim3(256), 0, s, reinterpret_cast<unsigned *>(p->state),
+                           p->state_words(), fu[0][0], fv[0][0], (size_t)B * p->npix(0));
+        HIP_TRY(hipGetLastError());
+    }
+
     for (int l = 0; l < L; l++) {
         const int h = p->dims[2 * l], w = p->dims[2 * l + 1];
         const size_t n = (size_t)h * w;
-        if (l == 0) {
-            // flow = zeros at the coarsest level (:182-184)
-            Prof pr(p, s, KC_MEMSET);
-            HIP_TRY(hipMemsetAsync(fu[0][0], 0, (size_t)B * n * sizeof(float), s));
-            HIP_TRY(hipMemsetAsync(fv[0][0], 0, (size_t)B * n * sizeof(float), s));
-        } else {
+        if (l > 0) {
             // upsample_flow (:195-197) from whichever slot holds level l-1's result
             const int hc = p->dims[2 * (l - 1)], wc = p->dims[2 * (l - 1) + 1];
             ResampleArgs r{};
@@ -593,7 +598,9 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
             // a plane sits s * (2*B*n_c) elements after slot 0
             r.in[0] = fu[l - 1][0];
             r.in[1] = fv[l - 1][0];
-            r.sel = p->sel(l - 1);
+            r.acc = p->acc();
+            r.acc_level = l - 1; r.L = L; r.K = p->Kc(); r.iters = K;
+            r.acc_thr = conv_threshold((double)p->npix(l - 1));
             r.in_sel_stride = (size_t)2 * B * p->npix(l - 1);
             r.out[0] = fu[l][0];
             r.out[1] = fv[l][0];
@@ -609,30 +616,17 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
         }
         const float *lp = (l == L - 1) ? d_prev : p->pyr[l];
         const float *lc = (l == L - 1) ? d_curr : p->pyr[l] + (size_t)B * n;
-        const int nblk = ((w + k5TX - 1) / k5TX) * ((h + k5TY - 1) / k5TY);
         for (int k = 0; k < K; k++) {
             LkArgs a{};
             a.prev = lp; a.curr = lc;
             a.fu[0] = fu[l][0]; a.fu[1] = fu[l][1];
             a.fv[0] = fv[l][0]; a.fv[1] = fv[l][1];
-            a.partial = p->partial;
-            a.sel = p->sel(l);
-            a.done = p->done(l);
+            a.acc = p->acc();
+            a.conv_thr = conv_threshold((double)n);
+            a.level = l; a.iter = k; a.L = L; a.K = p->Kc();
             a.H = h; a.W = w;
             rc = launch_lk<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, p->hw, a, B);
             if (rc) return rc;
-            FinalizeArgs f{};
-            f.partial = p->partial;
-            f.nblk = nblk;
-            f.count = (double)n;
-            f.log = p->log;
-            f.iters_run = p->iters_run();
-            f.sel = p->sel(l);
-            f.done = p->done(l);
-            f.level = l; f.iter = k; f.L = L; f.K = std::max(K, 1);
-            Prof pr(p, s, KC_FINALIZE);
-            hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, f);
-            HIP_TRY(hipGetLastError());
         }
     }
     // pairs whose finest level exited early hold their result in the internal slot
@@ -642,10 +636,18 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
         e.src_v = fv[L - 1][1 - want];
         e.dst_u = d_u;
         e.dst_v = d_v;
-        e.sel = p->sel(L - 1);
+        e.acc = p->acc();
         e.want = want;
+        e.L = L; e.K = p->Kc(); e.iters = K;
+        for (int l = 0; l < L; l++) {
+            e.counts[l] = (double)p->npix(l);
+            e.thr[l] = conv_threshold(e.counts[l]);
+        }
+        e.log = p->log();
+        e.iters_run = p->iters_run();
         e.plane = (size_t)p->H * p->W;
-        dim3 grid((unsigned)((e.plane + 1023) / 1024), B);
+        // few blocks per pair: the copy is the rare case, the common one is "nothing to do"
+        dim3 grid((unsigned)std::min<size_t>((e.plane + 255) / 256, 128), B);
         Prof pr(p, s, KC_EXPORT);
         hipLaunchKernelGGL(k_export_fixup, grid, dim3(256), 0, s, e);
         HIP_TRY(hipGetLastError());
@@ -659,7 +661,7 @@ OFLK_API int oflk_plan_read_log(oflk_plan *p, float *residual_log, int *iters_ru
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)stream;
     if (residual_log)
-        HIP_TRY(hipMemcpyAsync(residual_log, p->log,
+        HIP_TRY(hipMemcpyAsync(residual_log, p->log(),
                                (size_t)p->B * p->L * std::max(p->K, 1) * 2 * sizeof(float),
                                hipMemcpyDeviceToHost, s));
     if (iters_run)

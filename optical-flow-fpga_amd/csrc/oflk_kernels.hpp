@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+
+#include "../../include/oflk.h"
 #include <stdint.h>
 
 #pragma clang fp contract(off)
@@ -259,9 +261,11 @@ struct LkArgs {
     const float *aux;   // MODE_GRADS: It
     float *fu[2];       // flow ping-pong buffers, [B][H][W]; SINGLE/GRADS write fu[0]
     float *fv[2];
-    double *partial;    // ITER: [B][nblk][2] block sums of |du|, |dv|
-    const int *sel;     // ITER: per pair, which of fu[]/fv[] holds the current flow
-    const int *done;    // ITER: per pair, level already converged -> skip
+    // ITER: residual accumulators of the whole call, [B][L][K][kAccShards][kAccStride] (see lk_report /
+    // lk_level_state); this launch is iteration `iter` of level `level`
+    unsigned long long *acc;
+    int level, iter, L, K;
+    unsigned long long conv_thr;   // early-exit threshold of the level as a total (lk_level_state)
     int H, W;
     int B;              // frame pairs in the launch (k_lkw decodes pair/tile from a 1-D grid)
     // vertical chaining: tile rows [seg_row[s], seg_row[s+1]) form segment s, walked by one
@@ -459,32 +463,130 @@ template <int HW> struct LkGeom {
     static constexpr int AS = 4 * GW;                  // staging columns (72 or 80)
 };
 
+// ---------------------------------------------------------------------------
+// K6: per-pair residual means, convergence and ping-pong bookkeeping
+// (lucas_kanade_pyramidal.py:213-223) without a kernel of its own.
+//
+// Every block of an iteration launch adds its |du|, |dv| sums, as 64-bit fixed point, to
+// the accumulators of (pair, level, iteration) with two fire-and-forget device-scope atomics
+// (integer adds commute: the totals do not depend on the order in which blocks finish).  Global
+// atomics execute at the memory side and queue per line: with every block of a pair adding into
+// one 128-byte line a 1080p launch spent 9 us draining them, so each accumulator has eight
+// shards, picked by block id, 512 bytes apart (1.3 us).  Nothing in the same launch reads them.  Later launches on the stream -- the next iteration, the
+// flow upsample, the export at the end of the call -- see the final totals and each block
+// re-derives from them, with identical arithmetic, what a finalize step would have stored:
+// the means, how many iterations of the level were executed before the early exit
+// (:221-223) and hence which ping-pong slot holds the current flow.
+//
+// The reference's np.mean is an fp32 pairwise sum; the two agree to ~1e-7 relative, which can
+// flip the "< 0.01" test only when the mean sits within that distance of the threshold
+// (DESIGN.md "Known deviations").
+// ---------------------------------------------------------------------------
+constexpr int kAccShards = 8;
+constexpr int kAccStride = 64;   // u64 words between shards (512 B: every shard on a line, and likely a channel, of its own)
+constexpr double kAccScale = 1048576.0;       // 2^20 steps per pixel of |d|
+constexpr double kAccBlockMax = 268435456.0;  // 2^28: a block's sum is clamped here (also catches NaN)
+
+__device__ __forceinline__ size_t acc_index(int b, int l, int k, int L, int K)
+{
+    return ((((size_t)b * L + l) * K + k) * kAccShards) * kAccStride;
+}
+
+// one thread per block, after the block's last tile
+__device__ __forceinline__ void lk_report(const LkArgs &a, int b, double su, double sv)
+{
+    su = su < kAccBlockMax ? su : kAccBlockMax;
+    sv = sv < kAccBlockMax ? sv : kAccBlockMax;
+    unsigned long long *slot = a.acc + acc_index(b, a.level, a.iter, a.L, a.K) + kAccStride * (blockIdx.x & (kAccShards - 1));
+    __hip_atomic_fetch_add(slot + 0, (unsigned long long)__double2ll_rn(su * kAccScale), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(slot + 1, (unsigned long long)__double2ll_rn(sv * kAccScale), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// totals of iteration k (a finished launch)
+__device__ __forceinline__ void lk_totals(const unsigned long long *acc, int b, int l, int k, int L, int K,
+                                          unsigned long long &tu, unsigned long long &tv)
+{
+    const unsigned long long *s = acc + acc_index(b, l, k, L, K);
+    tu = 0;
+    tv = 0;
+#pragma unroll
+    for (int i = 0; i < kAccShards; i++) {
+        tu += s[kAccStride * i];
+        tv += s[kAccStride * i + 1];
+    }
+}
+
+// mean|du| (or |dv|) from a total: what np.mean(np.abs(d)) is compared and logged as
+__host__ __device__ inline float lk_mean_of(unsigned long long total, double count)
+{
+    return (float)(((double)total / kAccScale) / count);
+}
+
+struct LevelState {
+    int executed;   // iterations of the level run so far (the flow sits in slot executed & 1)
+    bool done;      // the early exit has fired
+};
+
+// State of (pair b, level l) before iteration k; k = K gives the level's final state.
+// `thr` is the smallest total whose mean is not below the exit threshold
+// (lk_mean_of(thr, count) >= 0.01f, found on the host with the same arithmetic), so the
+// test "mean < 0.01" (:221-223) is an integer compare here and costs every block a few
+// scalar operations instead of two fp64 divisions per thread.
+__device__ __forceinline__ LevelState lk_level_state(const unsigned long long *acc, int b, int l, int k, int L,
+                                                     int K, unsigned long long thr)
+{
+    LevelState st{0, false};
+    for (int j = 0; j < k && !st.done; j++) {
+        unsigned long long tu, tv;
+        lk_totals(acc, b, l, j, L, K, tu, tv);
+        st.executed = j + 1;
+        st.done = tu < thr && tv < thr;
+    }
+    return st;
+}
+
+// Start of a pyramidal call: zero the per-call state block and the coarsest level's flow
+// planes (lucas_kanade_pyramidal.py:182-184) in one launch.
+__global__ __launch_bounds__(256) void k_call_init(unsigned *__restrict__ state, size_t nwords,
+                                                   float *__restrict__ u0, float *__restrict__ v0, size_t n)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+    for (size_t i = t; i < nwords; i += nt) state[i] = 0u;
+    for (size_t i = t; i < n; i += nt) {
+        u0[i] = 0.0f;
+        v0[i] = 0.0f;
+    }
+}
+
 // Levels narrower or shorter than the window: no pixel has a full window, the reference's
 // loop (lucas_kanade_core.py:101-108) runs over nothing and d = 0 everywhere.  Launched in
 // place of k_lkw so that the tile kernel may assume H, W > 2*HW (in particular W >= 2).
 // grid: (ceil(H*W / 256), B)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_lk_degenerate(LkArgs a, int ntiles)
+__global__ __launch_bounds__(256) void k_lk_degenerate(LkArgs a)
 {
     const int b = blockIdx.y;
     const size_t plane = (size_t)a.H * (size_t)a.W;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     int sel = 0;
     if (MODE == MODE_ITER) {
-        if (a.done[b]) return;
-        sel = a.sel[b];
-        // |d| sums of every tile slot the finalize kernel adds up
-        if (e < (size_t)ntiles * 2) a.partial[(size_t)b * ntiles * 2 + e] = 0.0;
+        const LevelState st = lk_level_state(a.acc, b, a.level, a.iter, a.L, a.K, a.conv_thr);
+        if (st.done) return;
+        sel = st.executed & 1;
     }
-    if (e >= plane) return;
-    const size_t i = (size_t)b * plane + e;
-    if (MODE == MODE_ITER) {
-        a.fu[1 - sel][i] = a.fu[sel][i] + 0.0f;   // flow += d
-        a.fv[1 - sel][i] = a.fv[sel][i] + 0.0f;
-    } else {
-        a.fu[0][i] = 0.0f;
-        a.fv[0][i] = 0.0f;
+    if (e < plane) {
+        const size_t i = (size_t)b * plane + e;
+        if (MODE == MODE_ITER) {
+            a.fu[1 - sel][i] = a.fu[sel][i] + 0.0f;   // flow += d
+            a.fv[1 - sel][i] = a.fv[sel][i] + 0.0f;
+        } else {
+            a.fu[0][i] = 0.0f;
+            a.fv[0][i] = 0.0f;
+        }
     }
+    // d = 0: nothing to add to the accumulators; the iteration reads as converged
 }
 
 template <int HW, int MODE, bool VEC>
@@ -545,14 +647,16 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     }
     int sel = 0;
     if (MODE == MODE_ITER) {
-        if (a.done[b]) return;
-        sel = a.sel[b];
+        const LevelState st = lk_level_state(a.acc, b, a.level, a.iter, a.L, a.K, a.conv_thr);
+        if (st.done) return;
+        sel = st.executed & 1;
     }
     const size_t plane = (size_t)H * (size_t)W;
     const float *__restrict__ prev = a.prev + (size_t)b * plane;
     const float *__restrict__ curr = a.curr + (size_t)b * plane;
     const int x0 = tile_x * k5TX;
     float carry_a[NC], carry_i[NC];
+    double blk_u = 0.0, blk_v = 0.0;   // thread 0: |d| sums of the block's tiles
 
     for (int it = 0; it < ntile; it++) {
         // re-derived per tile behind an opaque move: otherwise every per-thread address of all
@@ -561,7 +665,6 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         asm volatile("" : "+v"(tid));
         const int tile_y = tile_y_first + it;
         const int y0 = tile_y * k5TY;
-        const int tile = (b * tiles_y + tile_y) * tiles_x + tile_x;   // slot of this tile's |d| sums
         const int rstart = (it == 0 || MODE == MODE_GRADS || OFLK_NOCHAIN) ? 0 : 2 * R;  // first staging row to compute
 
         float gix[NG], giy[NG], git[NG];
@@ -903,64 +1006,11 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         // stage 3 has read the planes (the next tile's staging overwrites them) and s_red is complete
         if (MODE == MODE_ITER || it + 1 < ntile) __syncthreads();
         if (MODE == MODE_ITER && tid == 0) {
-            double tu = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
-            double tv = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
-            a.partial[(size_t)tile * 2 + 0] = tu;   // slot = (b * tiles_y + tile_y) * tiles_x + tile_x
-            a.partial[(size_t)tile * 2 + 1] = tv;
+            blk_u += (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+            blk_v += (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// K6: per-pair residual means, log, convergence flag
-// (lucas_kanade_pyramidal.py:213-223).  One block per pair; fixed summation
-// order, fp64.  The reference's np.mean is an fp32 pairwise sum; the two agree
-// to ~1e-7 relative, which can flip the "< 0.01" test only when the mean sits
-// within that distance of the threshold (DESIGN.md "Known deviations").
-// ---------------------------------------------------------------------------
-struct FinalizeArgs {
-    const double *partial;  // [B][nblk][2]
-    int nblk;
-    double count;           // H*W of the level
-    float *log;             // [B][L][K][2]
-    int *iters_run;         // [B][L]
-    int *sel;               // [B] (this level)
-    int *done;              // [B] (this level)
-    int level, iter, L, K;
-};
-
-__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a)
-{
-    const int b = blockIdx.x;
-    if (a.done[b]) return;
-    const int tid = threadIdx.x;
-    double su = 0.0, sv = 0.0;
-    const double *p = a.partial + (size_t)b * a.nblk * 2;
-    for (int i = tid; i < a.nblk; i += 256) {
-        su += p[2 * i];
-        sv += p[2 * i + 1];
-    }
-    __shared__ double s_u[256], s_v[256];
-    s_u[tid] = su;
-    s_v[tid] = sv;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) {
-            s_u[tid] += s_u[tid + off];
-            s_v[tid] += s_v[tid + off];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        float mu = (float)(s_u[0] / a.count);
-        float mv = (float)(s_v[0] / a.count);
-        size_t li = (((size_t)b * a.L + a.level) * a.K + a.iter) * 2;
-        a.log[li] = mu;
-        a.log[li + 1] = mv;
-        a.iters_run[b * a.L + a.level] = a.iter + 1;
-        a.sel[b] ^= 1;
-        if (mu < 0.01f && mv < 0.01f) a.done[b] = 1;  // :221-223
-    }
+    if (MODE == MODE_ITER && threadIdx.x == 0) lk_report(a, b, blk_u, blk_v);
 }
 
 // ---------------------------------------------------------------------------
@@ -1015,7 +1065,12 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ in, floa
 struct ResampleArgs {
     const float *in[2];   // [nimg][H][W] each
     float *out[2];        // [nimg][Ho][Wo]
-    const int *sel;       // optional: per image, add sel[img]*in_sel_stride to in[] (flow ping-pong)
+    // optional (flow upsample): the source is the ping-pong slot that holds level `acc_level`'s
+    // final flow, slot * in_sel_stride elements after in[]
+    const unsigned long long *acc;
+    int acc_level, L, K;   // K: accumulator layout (>= 1)
+    int iters;             // iterations launched per level (0 when the plan has none)
+    unsigned long long acc_thr;
     size_t in_sel_stride; // elements between ping-pong buffers (0 when unused)
     float scale[2];
     int H, W, Ho, Wo;
@@ -1037,7 +1092,9 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
     const int H = a.H, W = a.W;
     const size_t ip = (size_t)H * W, op = (size_t)a.Ho * a.Wo;
     size_t selofs = 0;
-    if (a.sel) selofs = (size_t)a.sel[img] * a.in_sel_stride;
+    if (a.acc)
+        selofs = (size_t)(lk_level_state(a.acc, img, a.acc_level, a.iters, a.L, a.K, a.acc_thr).executed & 1) *
+                 a.in_sel_stride;
     // row part of map_coordinates(order=1, mode="constant")
     const double y = linspace_at(a.ly, i);
     const bool y_in = !(y < 0.0 || y > (double)(H - 1));
@@ -1273,7 +1330,9 @@ __global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
     const int H = a.H, W = a.W;
     const size_t ip = (size_t)H * W, op = (size_t)a.Ho * a.Wo;
     size_t selofs = 0;
-    if (a.sel) selofs = (size_t)a.sel[img] * a.in_sel_stride;
+    if (a.acc)
+        selofs = (size_t)(lk_level_state(a.acc, img, a.acc_level, a.iters, a.L, a.K, a.acc_thr).executed & 1) *
+                 a.in_sel_stride;
     // first coarse row / column any tap of this block touches (a sample that lands
     // exactly on the last index reads the mirrored index N-2 with weight 0)
     int ylo = (int)floor(linspace_at(a.ly, ib));
@@ -1430,22 +1489,48 @@ __global__ __launch_bounds__(256) void k_u8_to_f32(const unsigned char *__restri
 struct ExportArgs {
     const float *src_u, *src_v;  // internal buffers [B][H][W]
     float *dst_u, *dst_v;        // caller's buffers
-    const int *sel;              // [B]
+    const unsigned long long *acc;
     int want;                    // buffer index that is the caller's
+    int L, K;                    // K: accumulator / log layout (>= 1)
+    int iters;                   // iterations launched per level
+    double counts[OFLK_MAX_LEVELS];             // H*W per level
+    unsigned long long thr[OFLK_MAX_LEVELS];    // early-exit thresholds as totals
+    float *log;                  // [B][L][K][2]
+    int *iters_run;              // [B][L]
     size_t plane;
 };
 
+// End of a pyramidal call.  (1) Pairs whose finest level exited early hold their result in
+// the internal ping-pong slot: copy it to the caller's buffers.  (2) Block 0 of each pair
+// materialises the residual log and the per-level iteration counts from the accumulators.
 __global__ __launch_bounds__(256) void k_export_fixup(ExportArgs a)
 {
     const int b = blockIdx.y;
-    if (a.sel[b] == a.want) return;
-    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    const size_t base = (size_t)b * a.plane;
-    for (int k = 0; k < 4; k++) {
-        if (i + k < a.plane) {
-            a.dst_u[base + i + k] = a.src_u[base + i + k];
-            a.dst_v[base + i + k] = a.src_v[base + i + k];
+    for (int e = threadIdx.x; blockIdx.x == 0 && e < a.L * a.K; e += 256) {
+        // one thread per (level, iteration) log entry
+        const int l = e / a.K, k = e - l * a.K;
+        const LevelState st = lk_level_state(a.acc, b, l, a.iters, a.L, a.K, a.thr[l]);
+        if (k == 0) a.iters_run[b * a.L + l] = st.executed;
+        float mu = 0.0f, mv = 0.0f;
+        if (k < st.executed) {
+            unsigned long long tu, tv;
+            lk_totals(a.acc, b, l, k, a.L, a.K, tu, tv);
+            mu = lk_mean_of(tu, a.counts[l]);
+            mv = lk_mean_of(tv, a.counts[l]);
         }
+        const size_t li = (((size_t)b * a.L + l) * a.K + k) * 2;
+        a.log[li] = mu;
+        a.log[li + 1] = mv;
+    }
+    __shared__ int s_slot;
+    if (threadIdx.x == 0) s_slot = lk_level_state(a.acc, b, a.L - 1, a.iters, a.L, a.K, a.thr[a.L - 1]).executed & 1;
+    __syncthreads();
+    if (s_slot == a.want) return;
+    const size_t base = (size_t)b * a.plane;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.plane; i += step) {
+        a.dst_u[base + i] = a.src_u[base + i];
+        a.dst_v[base + i] = a.src_v[base + i];
     }
 }
 

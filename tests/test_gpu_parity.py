@@ -163,6 +163,21 @@ def test_pyramidal_matches_oracle_synthetic(P, oracle, shape, levels, win, iters
     _check_pyramidal(P, oracle, a, b, levels, win, iters)
 
 
+@pytest.mark.parametrize("shape,levels,win,iters", [
+    ((16, 20), 3, 5, 3),     # coarsest level 4 x 5: no pixel has a full window there
+    ((12, 12), 2, 5, 2),     # 6 x 6 coarse level: a 2 x 2 interior
+    ((9, 40), 3, 7, 2),      # every level is shorter than the window
+    ((40, 3), 1, 5, 3),      # narrower than the window
+    ((33, 47), 3, 5, 0),     # no iterations at all: the flow stays zero
+    ((48, 64), 2, 5, 1),
+])
+def test_pyramidal_degenerate_levels(P, oracle, shape, levels, win, iters):
+    """levels without interior pixels read as converged after one iteration (d = 0 everywhere)"""
+    rng = np.random.default_rng(shape[0] * 131 + shape[1])
+    a, b = _rand_pair(rng, *shape)
+    _check_pyramidal(P, oracle, a, b, levels, win, iters)
+
+
 def test_pyramidal_matches_oracle_noninteger(P, oracle):
     rng = np.random.default_rng(7)
     a, b = _rand_pair(rng, 90, 122)
