@@ -278,7 +278,8 @@ struct LkArgs {
 // K1/K7: the fused kernel k_lkw<HW, MODE, VEC>; the 5x5 window (window_size 4 or 5) is the
 // hot case and has a specialised sum stage.
 //
-// Tile 64 x 32 per 256-thread block, each thread 2 (x) x 4 (y) outputs.
+// Tile 64 x 24 per 256-thread block (OFLK_NY = 3), each thread 2 (x) x 3 (y) outputs; large
+// launches let one block walk several vertically adjacent tiles (see k_lkw).
 //
 // Exact window sums with fewer adds.  NumPy sums the 25 products a[0..24]
 // (row-major) as r[j] = (a[j] + a[j+8]) + a[j+16], j = 0..7, then
@@ -287,22 +288,20 @@ struct LkArgs {
 // products added in THE SAME order, hence bit-identical:
 //     r1(x,y) = r0(x+1,y)   r3(x,y) = r2(x+1,y)   r5(x,y) = r0(x,y+1)
 //     r6(x,y) = r0(x+1,y+1) r7(x,y) = r2(x,y+1)
-// so a 2x4 output patch needs 15 r0's, 14 r2's and 8 r4's (74 adds) instead of
-// 64 r's (128 adds); tree and tail are per output.  No rounding is changed.
+// so a 2x3 output patch needs 12 r0's, 12 r2's and 6 r4's (60 adds) instead of
+// 48 r's (96 adds); tree and tail are per output.  No rounding is changed.
 //
 // LDS layout: products interleaved as float2 {Ix*Ix, Iy*Iy}, float2 {Ix*Iy, Ix*It}
 // and float {Iy*It}, so the sums of two planes ride one v_pk_add_f32.  The
 // frame-average / It staging tiles alias the product planes (gradients wait in
 // registers across the barrier).
 // ---------------------------------------------------------------------------
+// build-time tuning knobs (defaults are the measured best on MI355X)
 #ifndef OFLK_NY
-#define OFLK_NY 3
-#endif
-#ifndef OFLK_NOCHAIN
-#define OFLK_NOCHAIN 0
+#define OFLK_NY 3      // output rows per thread: tile = 64 x 8*NY
 #endif
 #ifndef OFLK_BATCH
-#define OFLK_BATCH 4
+#define OFLK_BATCH 4   // warp cells whose gathers are in flight together (ITER stage 1)
 #endif
 // XCD-aware tile order (speed only, never correctness).  Workgroups of a 1-D grid are
 // dealt round-robin over the 8 XCDs (ids i and i+8 share an XCD, each with its own L2).
@@ -665,7 +664,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         asm volatile("" : "+v"(tid));
         const int tile_y = tile_y_first + it;
         const int y0 = tile_y * k5TY;
-        const int rstart = (it == 0 || MODE == MODE_GRADS || OFLK_NOCHAIN) ? 0 : 2 * R;  // first staging row to compute
+        const int rstart = (it == 0 || MODE == MODE_GRADS) ? 0 : 2 * R;  // first staging row to compute
 
         float gix[NG], giy[NG], git[NG];
         if (MODE == MODE_GRADS) {
@@ -1119,15 +1118,10 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const float *__restrict__ src = a.in[p] + selofs + (size_t)img * ip;
-#if defined(OFLK_RES_ABLATE) && OFLK_RES_ABLATE == 1
-            t[p][k][0] = (float)x0; t[p][k][1] = (float)x1; t[p][k][2] = (float)y0; t[p][k][3] = (float)(x0 + y1);
-            (void)src;
-#else
             t[p][k][0] = src[row0 + (unsigned)x0];
             t[p][k][1] = src[row0 + (unsigned)x1];
             t[p][k][2] = src[row1 + (unsigned)x0];
             t[p][k][3] = src[row1 + (unsigned)x1];
-#endif
         }
     }
 #pragma unroll
@@ -1145,11 +1139,7 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
             res[k] = r;
         }
         float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
-#if defined(OFLK_RES_ABLATE) && OFLK_RES_ABLATE == 2
-        if (res[0] == 123456.789f) {
-#else
         if ((a.Wo & 3) == 0) {
-#endif
             *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
         } else {
 #pragma unroll

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--window", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--identical", action="store_true", help="curr = prev (exercises early exit)")
+    ap.add_argument("--graph", action="store_true", help="also time one pass captured into a HIP graph")
     args = ap.parse_args()
     import torch
 
@@ -47,6 +48,23 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print(f"== {name} without per-kernel events: {e0.elapsed_time(e1) / args.reps * 1e3:.1f} us/call")
+        if args.graph:
+            # the plan only enqueues kernels: a caller may capture one pass into a HIP graph and replay it
+            side = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                call(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize()
+            g0 = torch.cuda.Event(enable_timing=True)
+            g1 = torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(args.reps):
+                g.replay()
+            g1.record()
+            torch.cuda.synchronize()
+            print(f"== {name} as a captured HIP graph: {g0.elapsed_time(g1) / args.reps * 1e3:.1f} us/call")
         plan.set_profiling(True)
         t0 = torch.cuda.Event(enable_timing=True)
         t1 = torch.cuda.Event(enable_timing=True)
