@@ -152,6 +152,22 @@ int oflk_plan_set_profiling(oflk_plan *plan, int enabled);
 int oflk_plan_kernel_times(oflk_plan *plan, const char **names, double *total_ms, long *launches,
                            int max_entries);
 
+/* ---- masked flow metrics on the device -------------------------------------- */
+/* compute_all_metrics(u_pred, v_pred, u_true, v_true, mask) of python/flow_metrics.py:166-201
+ * (mean_absolute_error :14-40, root_mean_square_error :43-70, endpoint_error :73-103,
+ * angular_error :106-163) for the rectangular test regions the verifier builds
+ * (mask[y0:y1, x0:x1] = True with NumPy slice semantics, python/optical_flow_verifier.py:96-138).
+ *   u_true, v_true : host arrays [B], the constant ground-truth vector of each pair
+ *   out            : host array [B][5] = mae_u, mae_v, rmse, epe, aae (degrees)
+ * Element-wise arithmetic is the reference's fp32; sums and arccos are fp64, so values agree
+ * with the reference's fp32 pairwise means to ~1e-6 relative (not bit for bit).
+ * oflk_plan_metrics reads device-resident flows [B][H][W] of the plan's shape and
+ * synchronises `stream`; oflk_flow_metrics takes host arrays. */
+int oflk_plan_metrics(oflk_plan *plan, const float *d_u, const float *d_v, const float *u_true,
+                      const float *v_true, int y0, int y1, int x0, int x1, double *out, void *stream);
+int oflk_flow_metrics(const float *u, const float *v, int B, int H, int W, const float *u_true,
+                      const float *v_true, int y0, int y1, int x0, int x1, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -905,6 +905,85 @@ OFLK_API int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *c
     return oflk_plan_read_log(p, residual_log, iters_run, nullptr);
 }
 
+namespace {
+
+// device flows -> metrics; `dev_true` holds u_true[B] then v_true[B]
+int metrics_device(const float *d_u, const float *d_v, int B, int H, int W, const float *u_true, const float *v_true,
+                   int y0, int y1, int x0, int x1, double *out, hipStream_t s)
+{
+    if (!d_u || !d_v || !u_true || !v_true || !out) return fail(OFLK_ERR_INVALID, "NULL argument");
+    if (B < 1 || H < 1 || W < 1) return fail(OFLK_ERR_INVALID, "B, H and W must be >= 1");
+    // NumPy slice semantics for mask[y0:y1, x0:x1]: negative bounds count from the end, then clip
+    auto norm = [](int i, int n) { return std::min(std::max(i < 0 ? i + n : i, 0), n); };
+    y0 = norm(y0, H); y1 = norm(y1, H); x0 = norm(x0, W); x1 = norm(x1, W);
+    const size_t count = (size_t)std::max(y1 - y0, 0) * (size_t)std::max(x1 - x0, 0);
+    Arena ar;
+    float *d_true = nullptr;
+    double *d_part = nullptr;
+    int rc = ar.get(&d_true, (size_t)2 * B);
+    if (!rc) rc = ar.get(&d_part, (size_t)B * kMetricBlocks * kMetricTerms);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_true, u_true, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_true + B, v_true, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    MetricArgs a{};
+    a.u = d_u; a.v = d_v;
+    a.u_true = d_true; a.v_true = d_true + B;
+    a.H = H; a.W = W;
+    a.y0 = y0; a.y1 = y1; a.x0 = x0; a.x1 = x1;
+    a.partial = d_part;
+    hipLaunchKernelGGL(k_flow_metrics, dim3(kMetricBlocks, (unsigned)B), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> part((size_t)B * kMetricBlocks * kMetricTerms);
+    HIP_TRY(hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int b = 0; b < B; b++) {
+        double t[kMetricTerms] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < kMetricBlocks; k++) {
+            const double *q = &part[((size_t)b * kMetricBlocks + k) * kMetricTerms];
+            for (int i = 0; i < kMetricTerms - 1; i++) t[i] += q[i];
+            t[kMetricTerms - 1] = std::max(t[kMetricTerms - 1], q[kMetricTerms - 1]);
+        }
+        double *o = out + (size_t)b * 5;
+        const double n = (double)count;   // an empty mask gives nan, as np.mean of an empty array does
+        o[0] = (double)(float)(t[0] / n);
+        o[1] = (double)(float)(t[1] / n);
+        o[2] = (double)std::sqrt((float)(t[2] / n));   // np.sqrt of the fp32 mean (:69)
+        o[3] = (double)(float)(t[3] / n);
+        // "nothing moves and nothing was predicted" (:143-146)
+        const double mt = std::sqrt((double)u_true[b] * u_true[b] + (double)v_true[b] * v_true[b]);
+        o[4] = (mt < 1e-6 && t[5] < (double)1e-6f) ? 0.0 : (double)(float)(t[4] / n);
+    }
+    return OFLK_OK;
+}
+
+}  // namespace
+
+OFLK_API int oflk_plan_metrics(oflk_plan *p, const float *d_u, const float *d_v, const float *u_true,
+                               const float *v_true, int y0, int y1, int x0, int x1, double *out, void *stream)
+{
+    if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    return metrics_device(d_u, d_v, p->B, p->H, p->W, u_true, v_true, y0, y1, x0, x1, out, (hipStream_t)stream);
+}
+
+OFLK_API int oflk_flow_metrics(const float *u, const float *v, int B, int H, int W, const float *u_true,
+                               const float *v_true, int y0, int y1, int x0, int x1, double *out)
+{
+    int rc = check_hw(u, v, H, W);
+    if (rc) return rc;
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    std::lock_guard<std::mutex> lk(g_mu);
+    rc = ensure_device(g_device);
+    if (rc) return rc;
+    Arena ar;
+    const size_t n = (size_t)B * H * W;
+    float *d_u = nullptr, *d_v = nullptr;
+    if ((rc = ar.get(&d_u, n)) || (rc = ar.get(&d_v, n))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_u, u, n * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d_v, v, n * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    return metrics_device(d_u, d_v, B, H, W, u_true, v_true, y0, y1, x0, x1, out, nullptr);
+}
+
 OFLK_API int oflk_u8_to_f32(const unsigned char *d_in, float *d_out, size_t n, void *stream)
 {
     if (!d_in || !d_out) return fail(OFLK_ERR_INVALID, "NULL argument");

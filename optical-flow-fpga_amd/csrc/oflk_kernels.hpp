@@ -1524,4 +1524,73 @@ __global__ __launch_bounds__(256) void k_export_fixup(ExportArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// F1: masked flow metrics on the device (python/flow_metrics.py:14-201) for the rectangular
+// test regions the verifier uses (mask[y0:y1, x0:x1] = True, optical_flow_verifier.py:96-138),
+// so that a batch run need not copy flow fields to the host.
+//
+// Per pixel the reference's own fp32 operations (error components, squares, square roots,
+// the (u, v, 1) dot product and norms); arccos and the sums in fp64.  The reference takes
+// fp32 pairwise means and NumPy's fp32 arccos, so the two agree to ~1e-6 relative, not bit
+// for bit (tolerance stated in tests/test_gpu_metrics.py).
+// grid (kMetricBlocks, B); out: [B][kMetricBlocks][kMetricTerms] partial sums, added up in a fixed
+// order on the host.
+// ---------------------------------------------------------------------------
+constexpr int kMetricBlocks = 64;
+constexpr int kMetricTerms = 6;   // sum|eu|, sum|ev|, sum(eu^2+ev^2), sum sqrt(..), sum angle [deg], max |pred|
+
+struct MetricArgs {
+    const float *u, *v;      // [B][H][W]
+    const float *u_true;     // [B] device
+    const float *v_true;     // [B]
+    int H, W;
+    int y0, y1, x0, x1;      // mask rectangle, already clipped to the frame
+    double *partial;         // [B][kMetricBlocks][kMetricTerms]
+};
+
+__global__ __launch_bounds__(256) void k_flow_metrics(MetricArgs a)
+{
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)a.H * (size_t)a.W;
+    const float *__restrict__ u = a.u + (size_t)b * plane;
+    const float *__restrict__ v = a.v + (size_t)b * plane;
+    const float ut = a.u_true[b], vt = a.v_true[b];
+    const int rw = a.x1 - a.x0, rh = a.y1 - a.y0;
+    const size_t n = (size_t)max(rw, 0) * (size_t)max(rh, 0);
+    // |(ut, vt, 1)|: fp32 ops in the reference's order (flow_metrics.py:150)
+    const float norm_t = sqrtf(ut * ut + vt * vt + 1.0f);
+    double s[kMetricTerms] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)kMetricBlocks * 256) {
+        const int y = a.y0 + (int)(e / (size_t)rw), x = a.x0 + (int)(e % (size_t)rw);
+        const float up = u[(size_t)y * a.W + x], vp = v[(size_t)y * a.W + x];
+        const float eu = up - ut, ev = vp - vt;           // :31-32
+        const float sq = eu * eu + ev * ev;               // :66, :99
+        const float mag2 = up * up + vp * vp;
+        const float norm_p = sqrtf(mag2 + 1.0f);          // :149
+        float c = (up * ut + vp * vt + 1.0f) / (norm_p * norm_t);   // :153-155
+        c = fminf(fmaxf(c, -1.0f), 1.0f);                 // :158
+        s[0] += (double)fabsf(eu);
+        s[1] += (double)fabsf(ev);
+        s[2] += (double)sq;
+        s[3] += (double)sqrtf(sq);
+        s[4] += acos((double)c) * 57.29577951308232;      // :161-162
+        s[5] = fmax(s[5], (double)sqrtf(mag2));           // :143 (for the "nothing moves" case)
+    }
+    __shared__ double red[kMetricTerms][256];
+#pragma unroll
+    for (int t = 0; t < kMetricTerms; t++) red[t][threadIdx.x] = s[t];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+#pragma unroll
+            for (int t = 0; t < kMetricTerms - 1; t++) red[t][threadIdx.x] += red[t][threadIdx.x + off];
+            red[kMetricTerms - 1][threadIdx.x] =
+                fmax(red[kMetricTerms - 1][threadIdx.x], red[kMetricTerms - 1][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < kMetricTerms)
+        a.partial[((size_t)b * kMetricBlocks + blockIdx.x) * kMetricTerms + threadIdx.x] = red[threadIdx.x][0];
+}
+
 }  // namespace oflk

@@ -54,6 +54,8 @@ SIGNATURES = {
     "oflk_plan_pyramidal": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "oflk_plan_read_log": (ctypes.c_int, [_vp, _f32p, _i32p, _vp]),
     "oflk_plan_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "oflk_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _vp]),
+    "oflk_flow_metrics": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "oflk_plan_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
 }
 
@@ -163,6 +165,16 @@ class Plan:
         runs = np.zeros((self.B, self.levels), np.int32)
         check(lib().oflk_plan_read_log(self._h, ptr(log), runs.ctypes.data_as(_i32p), stream))
         return log, runs
+
+    def metrics(self, d_u: int, d_v: int, u_true, v_true, region, stream: int = 0) -> np.ndarray:
+        """[B][5] = mae_u, mae_v, rmse, epe, aae of device-resident flows over mask[y0:y1, x0:x1]."""
+        ut = np.ascontiguousarray(u_true, np.float32).reshape(self.B)
+        vt = np.ascontiguousarray(v_true, np.float32).reshape(self.B)
+        out = np.zeros((self.B, 5), np.float64)
+        y0, y1, x0, x1 = (int(r) for r in region)
+        check(lib().oflk_plan_metrics(self._h, d_u, d_v, ptr(ut), ptr(vt), y0, y1, x0, x1,
+                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), stream))
+        return out
 
     def set_profiling(self, enabled) -> None:
         """False/0 off, True/1 every kernel, 2 only the dominant kernel (finest-level LK iteration)."""

@@ -129,3 +129,17 @@ def test_flow_text_dump_format(tmp_path):
     assert lines[:4] == ["# Optical flow field data (Python reference)", "# Format: x y u v", "# Image size: 3x2",
                          "# Test region: x[0:1], y[0:1]"]
     assert lines[4] == "0 0 0.000000 -0.000000" and lines[-1] == "2 1 1.250000 -1.250000" and len(lines) == 10
+
+
+def test_mask_rectangle_of_the_verifier_regions():
+    """flow_metrics.mask_rectangle recovers the slice bounds of get_test_region_mask's masks"""
+    import flow_metrics as M
+    import optical_flow_verifier as V
+
+    assert M.mask_rectangle(V.get_test_region_mask((240, 320), "translate_small", 80)) == (10, 230, 10, 310)
+    assert M.mask_rectangle(V.get_test_region_mask((240, 320), "rotate_small", 80)) == (80, 160, 120, 200)
+    assert M.mask_rectangle(np.zeros((4, 4), bool)) == (0, 0, 0, 0)
+    bad = np.ones((6, 6), bool)
+    bad[2, 3] = False
+    with pytest.raises(ValueError):
+        M.mask_rectangle(bad)
