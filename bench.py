@@ -110,7 +110,7 @@ def main() -> None:
         step()
     fence()
     # timed region: HIP event pairs (on the launch stream) around the dominant kernel only --
-    # bracketing all ~30 launches of a step costs ~4.5 % of the step time
+    # bracketing all ~17 launches of a step costs ~3 % of the step time
     plan.set_profiling(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -166,6 +166,23 @@ def main() -> None:
                    "share": round(t["total_ms"] / max(sum(x["total_ms"] for x in ktimes.values()), 1e-12), 4)}
                for k, t in ktimes.items() if t["launches"]}
 
+    # ---- one pair per call (BASELINE config 3 read literally): latency-bound, informational ----
+    one_pair = None
+    if rank == 0 and world == 1:
+        plan1 = _oflk.Plan(local_rank, 1, H, W, L, args.window, K)
+        for _ in range(5):
+            plan1.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        nrep = 100
+        for _ in range(nrep):
+            plan1.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
+        torch.cuda.synchronize()
+        q1 = time.perf_counter()
+        plan1.close()
+        one_pair = {"us_per_call": round(1e6 * (q1 - q0) / nrep, 1), "Mpix/s": round(nrep * H * W / (q1 - q0) / 1e6, 1),
+                    "note": "batch of 1: ~17 dependent kernel launches, not the throughput figure"}
+
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1) --------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -213,6 +230,7 @@ def main() -> None:
             "roofline": roofline,
             "whole_call": whole,
             "kernels": kernels,
+            "one_pair_per_call": one_pair,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
