@@ -168,8 +168,12 @@ __device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx,
     LeanTaps t;
     const double y = (double)gy + (double)v;   // int64 + float32 -> float64, as the reference
     const double x = (double)gx + (double)u;
-    // bitwise, not short-circuit: four compares and three scalar ANDs, no branches
-    t.inside = (y >= 0.0) & (y <= g.Hm1) & (x >= 0.0) & (x <= g.Wm1);
+    // 0 <= y <= H-1 as ONE unsigned compare of the bit patterns: non-negative doubles order like
+    // their bits, and a set sign bit (y < 0; y = -0.0 cannot come out of the sum above) or a NaN
+    // reads as larger than any in-range value.  Two compares and one scalar AND, no branches.
+    const int in_y = (unsigned long long)__double_as_longlong(y) <= (unsigned long long)__double_as_longlong(g.Hm1);
+    const int in_x = (unsigned long long)__double_as_longlong(x) <= (unsigned long long)__double_as_longlong(g.Wm1);
+    t.inside = (in_y & in_x) != 0;
     const double fy = fmin(floor(y), g.Hm2), fx = fmin(floor(x), g.Wm2);
     const double ry = y - fy, rx = x - fx;
     t.wy0 = 1.0 - ry;
@@ -198,8 +202,10 @@ __device__ __forceinline__ void lean_load(const LeanGeom &g, const float *__rest
 
 __device__ __forceinline__ float lean_finish(const LeanTaps &t, PairF r0, PairF r1)
 {
-    double acc = 0.0, c;
-    c = (double)r0.a; c = c * t.wy0; c = c * t.wx0; acc = acc + c;
+    // SciPy starts the sum at +0.0; adding the first term to it only matters for the sign of an
+    // all-zero result (-0.0 vs +0.0, equal as values), so the sum starts at the first term
+    double acc, c;
+    c = (double)r0.a; c = c * t.wy0; acc = c * t.wx0;
     c = (double)r0.b; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
     c = (double)r1.a; c = c * t.wy1; c = c * t.wx0; acc = acc + c;
     c = (double)r1.b; c = c * t.wy1; c = c * t.wx1; acc = acc + c;
