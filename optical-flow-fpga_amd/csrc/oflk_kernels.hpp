@@ -1253,14 +1253,17 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
     }
     __syncthreads();
 
-    // ---- C: horizontal pass; thread = one row, 11 consecutive columns --------
+    // ---- C: horizontal pass; thread = one row, 10 consecutive columns (34 rows x 7 segments =
+    // 238 busy lanes; the last segment's surplus columns are computed but not stored) --------
     {
-        constexpr int CS = 11;                       // cols per thread (6 segments cover 66)
+        constexpr int CS = 10;                       // cols per thread (7 segments cover 66)
+        constexpr int NSEG = (kPBW + CS - 1) / CS;
+        static_assert(kPBH * NSEG <= 256, "one thread per (row, segment)");
         const int row = tid % kPBH, seg = tid / kPBH;
-        if (seg < 6) {
+        if (seg < NSEG) {
             float win[CS + 16];
 #pragma unroll
-            for (int k = 0; k < CS + 16; k++) win[k] = s_v[row * kPVS + seg * CS + k];
+            for (int k = 0; k < CS + 16; k++) win[k] = s_v[row * kPVS + min(seg * CS + k, kPIW - 1)];
 #pragma unroll
             for (int o = 0; o < CS; o++) {
                 double t = (double)win[o + 8] * a.w[0];
@@ -1270,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
                     double m = sgm * a.w[k];
                     t = t + m;
                 }
-                s_h[row * kPHS + seg * CS + o] = (float)t;
+                if (seg * CS + o < kPBW) s_h[row * kPHS + seg * CS + o] = (float)t;
             }
         }
     }
