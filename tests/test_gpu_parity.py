@@ -264,6 +264,36 @@ def test_full_size_pyramidal_matches_oracle(P, oracle, shape):
         oracle.set_threads(1)
 
 
+def test_bench_workload_batch_equals_single_pair_calls(P):
+    """bench.py's launch shape: 32 pairs of 1080p in one call.  Large launches take the chained-tile
+    path of the iteration kernel (a block walks several vertically adjacent tiles and carries their
+    shared staging rows); a one-pair call does not.  Both must give the same flow, value for value --
+    and the one-pair call is held to the oracle by test_full_size_pyramidal_matches_oracle."""
+    import ctypes
+
+    import _oflk
+    from oflk_synth import synth_pair
+
+    B, H, W, L, K = 32, 1080, 1920, 3, 3
+    distinct = [synth_pair(H, W, pair_index=1), synth_pair(H, W, pair_index=6, dx=-2.25, dy=0.75)]
+    single = [P.lucas_kanade_pyramidal_with_log(a, b, L, 5, K) for a, b in distinct]
+    prev = np.stack([distinct[i % 2][0] for i in range(B)])
+    curr = np.stack([distinct[i % 2][1] for i in range(B)])
+    u = np.empty_like(prev)
+    v = np.empty_like(prev)
+    log = np.zeros((B, L, K, 2), np.float32)
+    runs = np.zeros((B, L), np.int32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    _oflk.check(_oflk.lib().oflk_pyramidal_batch(prev.ctypes.data_as(f32p), curr.ctypes.data_as(f32p), B, H, W, L, 5, K,
+                                                 u.ctypes.data_as(f32p), v.ctypes.data_as(f32p),
+                                                 log.ctypes.data_as(f32p), runs.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+    for i in range(B):
+        su, sv, slog, sruns = single[i % 2]
+        assert np.array_equal(u[i], su) and np.array_equal(v[i], sv), f"pair {i}"
+        assert list(runs[i]) == list(sruns)
+        np.testing.assert_allclose(log[i], slog, rtol=2e-6, atol=1e-9)
+
+
 def test_640x480_single_scale_matches_oracle(K, oracle):
     """configs[1]"""
     from oflk_synth import synth_pair
