@@ -263,7 +263,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     const long per_slot = (long)B * tiles_x * tiles_y / resident;
     int cap = MODE == MODE_GRADS ? 1 : (int)std::min<long>(std::max(1, cap_env), per_slot / 5);
     cap = std::max(cap, (tiles_y + kMaxSegs / 2 - 1) / (kMaxSegs / 2));  // keep the table short
-    if (MODE == MODE_GRADS || cap_env <= 1 || per_slot < 10) cap = 1;
+    if (MODE == MODE_GRADS || hw > 2 || cap_env <= 1 || per_slot < 10) cap = 1;   // kLkChain
     unsigned nblocks;
     if (cap <= 1) {
         a.nseg = 0;

@@ -594,6 +594,10 @@ __global__ __launch_bounds__(256) void k_lk_degenerate(LkArgs a)
     // d = 0: nothing to add to the accumulators; the iteration reads as converged
 }
 
+// does k_lkw<HW, MODE> support walking several tiles per block (vertical chaining)?
+template <int HW, int MODE>
+constexpr bool kLkChain = HW <= 2 && MODE != MODE_GRADS;
+
 template <int HW, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
 {
@@ -626,8 +630,11 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     // 24 new rows per tile instead of 30.
     const int H = a.H, W = a.W;
     const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
+    // windows above 5x5 run one tile per block: their sum stage needs the registers the loop
+    // and the carried rows would take (7x7: 153 -> 172 VGPRs, 3 -> 2 waves per SIMD)
+    constexpr bool CHAIN = kLkChain<HW, MODE>;
     int b, tile_x, tile_y_first, ntile;
-    if (a.nseg == 0) {
+    if (!CHAIN || a.nseg == 0) {
         const int tile = xcd_tile_index(blockIdx.x, tiles_x * tiles_y * a.B);
         b = tile / (tiles_x * tiles_y);
         const int t = tile - b * (tiles_x * tiles_y);
@@ -663,14 +670,14 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     float carry_a[NC], carry_i[NC];
     double blk_u = 0.0, blk_v = 0.0;   // thread 0: |d| sums of the block's tiles
 
-    for (int it = 0; it < ntile; it++) {
+    for (int it = 0; it < (CHAIN ? ntile : 1); it++) {
         // re-derived per tile behind an opaque move: otherwise every per-thread address of all
         // three stages is hoisted out of the loop and held in registers (occupancy 4 -> 2)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int tile_y = tile_y_first + it;
         const int y0 = tile_y * k5TY;
-        const int rstart = (it == 0 || MODE == MODE_GRADS) ? 0 : 2 * R;  // first staging row to compute
+        const int rstart = (!CHAIN || it == 0) ? 0 : 2 * R;  // first staging row to compute
 
         float gix[NG], giy[NG], git[NG];
         if (MODE == MODE_GRADS) {
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
             }
         } else {
             // ---- stage 1: second frame (warped if ITER), frame average, It -------
-            if (it > 0) {
+            if (CHAIN && it > 0) {
                 // rows 0 .. 2R-1 are the previous tile's rows TY .. AH-1
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                 giy[k] = iy;
                 git[k] = s_it[(r + 1) * AS + (c + GC)];
             }
-            if (it + 1 < ntile) {
+            if (CHAIN && it + 1 < ntile) {
                 // staging rows TY .. AH-1 are the next tile's rows 0 .. 2R-1
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
@@ -1009,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
             }
         }
         // stage 3 has read the planes (the next tile's staging overwrites them) and s_red is complete
-        if (MODE == MODE_ITER || it + 1 < ntile) __syncthreads();
+        if (MODE == MODE_ITER || (CHAIN && it + 1 < ntile)) __syncthreads();
         if (MODE == MODE_ITER && tid == 0) {
             blk_u += (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
             blk_v += (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
