@@ -359,13 +359,46 @@ int launch_upsample(oflk_plan *plan, hipStream_t s, const ResampleArgs &r, int n
     return OFLK_OK;
 }
 
+// what the first pyramid launch of a pyramidal call carries besides its own work
+struct PyrExtra {
+    const float *in2 = nullptr;   // images nsplit .. nimg-1 (the second caller buffer)
+    int nsplit = 0;
+    unsigned *zero_words = nullptr;   // per-call state to clear
+    size_t n_zero_words = 0;
+    float *zero_u = nullptr, *zero_v = nullptr;   // coarsest-level flow planes to clear
+    size_t n_zero_flow = 0;
+};
+
+int launch_call_init(oflk_plan *plan, hipStream_t s, const PyrExtra &x)
+{
+    Prof pr(plan, s, KC_INIT);
+    hipLaunchKernelGGL(k_call_init, dim3(256), dim3(256), 0, s, x.zero_words, x.n_zero_words, x.zero_u, x.zero_v,
+                       x.n_zero_flow);
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
 // gaussian blur + linspace resample of `nimg` images: in [nimg][h][w] -> out [nimg][ho][wo]
 int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const float *in, float *out,
-                    float *tmpA, float *tmpB, int nimg, int h, int w, int ho, int wo)
+                    float *tmpA, float *tmpB, int nimg, int h, int w, int ho, int wo,
+                    const PyrExtra *extra = nullptr)
 {
     if (pyr_fused_fits(h, w, ho, wo, gauss)) {
         PyrArgs a{};
         a.in = in;
+        a.in2 = in;
+        a.nsplit = nimg;
+        if (extra) {
+            if (extra->in2) {
+                a.in2 = extra->in2;
+                a.nsplit = extra->nsplit;
+            }
+            a.zero_words = extra->zero_words;
+            a.n_zero_words = extra->n_zero_words;
+            a.zero_u = extra->zero_u;
+            a.zero_v = extra->zero_v;
+            a.n_zero_flow = extra->n_zero_flow;
+        }
         a.out = out;
         a.H = h; a.W = w; a.Ho = ho; a.Wo = wo;
         a.ly = make_linspace(h, ho);
@@ -376,6 +409,19 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
         hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         return OFLK_OK;
+    }
+    if (extra) {
+        // unfused path: the extras become launches of their own
+        if (extra->zero_words) {
+            int rc = launch_call_init(plan, s, *extra);
+            if (rc) return rc;
+        }
+        if (extra->in2) {
+            int rc = launch_pyr_down(plan, gauss, s, in, out, tmpA, tmpB, extra->nsplit, h, w, ho, wo);
+            if (rc) return rc;
+            return launch_pyr_down(plan, gauss, s, extra->in2, out + (size_t)extra->nsplit * ho * wo, tmpA, tmpB,
+                                   nimg - extra->nsplit, h, w, ho, wo);
+        }
     }
     {
         Prof pr(plan, s, KC_BLUR);
@@ -547,23 +593,6 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
     const int B = p->B, L = p->L, K = p->K;
     int rc;
 
-    // ---- pyramids (lucas_kanade_pyramidal.py:173-174), fine -> coarse ---------
-    for (int l = L - 2; l >= 0; l--) {
-        int h = p->dims[2 * (l + 1)], w = p->dims[2 * (l + 1) + 1];
-        int ho = p->dims[2 * l], wo = p->dims[2 * l + 1];
-        size_t no = (size_t)ho * wo;
-        if (l == L - 2) {
-            // the finest level is the caller's frames (image.copy() at :40 is a no-op here)
-            rc = launch_pyr_down(p, p->gauss, s, d_prev, p->pyr[l], p->tmpA, p->tmpB, B, h, w, ho, wo);
-            if (rc) return rc;
-            rc = launch_pyr_down(p, p->gauss, s, d_curr, p->pyr[l] + (size_t)B * no, p->tmpA, p->tmpB, B, h, w, ho, wo);
-            if (rc) return rc;
-        } else {
-            rc = launch_pyr_down(p, p->gauss, s, p->pyr[l + 1], p->pyr[l], p->tmpA, p->tmpB, 2 * B, h, w, ho, wo);
-            if (rc) return rc;
-        }
-    }
-
     // the caller's buffers are the ping-pong slot the final flow lands in when no
     // level exits early at the finest level: slot K % 2
     const int want = K & 1;
@@ -578,13 +607,34 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
     fu[L - 1][1 - want] = p->fu(L - 1, 0);
     fv[L - 1][1 - want] = p->fv(L - 1, 0);
 
-    // ---- per-call state (acc, arrived, sel, done, iters_run, log) = 0 and, in the same
-    // launch, flow = zeros at the coarsest level (:182-184) ------------------------
-    {
-        Prof pr(p, s, KC_INIT);
-        hipLaunchKernelGGL(k_call_init, dim3(256), dim3(256), 0, s, reinterpret_cast<unsigned *>(p->state),
-                           p->state_words(), fu[0][0], fv[0][0], (size_t)B * p->npix(0));
-        HIP_TRY(hipGetLastError());
+    // per-call state (acc, iters_run, log) = 0 and flow = zeros at the coarsest level (:182-184):
+    // carried by the first pyramid launch, or a launch of its own when there is no pyramid
+    PyrExtra first;
+    first.zero_words = reinterpret_cast<unsigned *>(p->state);
+    first.n_zero_words = p->state_words();
+    first.zero_u = fu[0][0];
+    first.zero_v = fv[0][0];
+    first.n_zero_flow = (size_t)B * p->npix(0);
+    if (L == 1) {
+        rc = launch_call_init(p, s, first);
+        if (rc) return rc;
+    }
+
+    // ---- pyramids (lucas_kanade_pyramidal.py:173-174), fine -> coarse ---------
+    for (int l = L - 2; l >= 0; l--) {
+        int h = p->dims[2 * (l + 1)], w = p->dims[2 * (l + 1) + 1];
+        int ho = p->dims[2 * l], wo = p->dims[2 * l + 1];
+        if (l == L - 2) {
+            // the finest level is the caller's frames (image.copy() at :40 is a no-op here):
+            // prev and curr in one launch, images 0..B-1 from d_prev, B..2B-1 from d_curr
+            first.in2 = d_curr;
+            first.nsplit = B;
+            rc = launch_pyr_down(p, p->gauss, s, d_prev, p->pyr[l], p->tmpA, p->tmpB, 2 * B, h, w, ho, wo, &first);
+            if (rc) return rc;
+        } else {
+            rc = launch_pyr_down(p, p->gauss, s, p->pyr[l + 1], p->pyr[l], p->tmpA, p->tmpB, 2 * B, h, w, ho, wo);
+            if (rc) return rc;
+        }
     }
 
     for (int l = 0; l < L; l++) {

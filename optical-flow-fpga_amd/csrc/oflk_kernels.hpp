@@ -1186,8 +1186,16 @@ constexpr int kPVS = kPIW + 1;               // row stride of the vertical-pass 
 constexpr int kPHS = kPBW + 1;               // row stride of the blurred tile
 
 struct PyrArgs {
-    const float *in;   // [nimg][H][W]
+    const float *in;   // [nimg][H][W]; images nsplit .. come from in2 instead (two caller buffers, one launch)
+    const float *in2;
+    int nsplit;
     float *out;        // [nimg][Ho][Wo]
+    // optional, at the start of a pyramidal call: words to zero (per-call state) and the coarsest
+    // level's flow planes (lucas_kanade_pyramidal.py:182-184), so that no launch of its own is needed
+    unsigned *zero_words;
+    size_t n_zero_words;
+    float *zero_u, *zero_v;
+    size_t n_zero_flow;
     int H, W, Ho, Wo;
     Linspace ly, lx;
     double w[9];       // gaussian weights, w[k] at distance k
@@ -1203,7 +1211,18 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W;
     const size_t ip = (size_t)H * (size_t)W, op = (size_t)a.Ho * (size_t)a.Wo;
-    const float *__restrict__ src = a.in + (size_t)blockIdx.z * ip;
+    const int img = blockIdx.z;
+    const float *__restrict__ src = img < a.nsplit ? a.in + (size_t)img * ip : a.in2 + (size_t)(img - a.nsplit) * ip;
+    if (a.zero_words) {
+        // grid-stride over all blocks of the launch
+        const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (size_t i = blk * 256 + threadIdx.x; i < a.n_zero_words; i += nblk * 256) a.zero_words[i] = 0u;
+        for (size_t i = blk * 256 + threadIdx.x; i < a.n_zero_flow; i += nblk * 256) {
+            a.zero_u[i] = 0.0f;
+            a.zero_v[i] = 0.0f;
+        }
+    }
     const int j0 = blockIdx.x * kPTW, i0 = blockIdx.y * kPTH;
     // first blurred row / column any tap of this tile touches (a sample that lands
     // exactly on the last row reads the mirrored row H-2 with weight 0)
