@@ -110,7 +110,7 @@ def main() -> None:
         step()
     fence()
     # timed region: HIP event pairs (on the launch stream) around the dominant kernel only --
-    # bracketing all ~17 launches of a step costs ~3 % of the step time
+    # bracketing all 15 launches of a step costs ~3 % of the step time
     plan.set_profiling(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -181,7 +181,7 @@ def main() -> None:
         q1 = time.perf_counter()
         plan1.close()
         one_pair = {"us_per_call": round(1e6 * (q1 - q0) / nrep, 1), "Mpix/s": round(nrep * H * W / (q1 - q0) / 1e6, 1),
-                    "note": "batch of 1: ~17 dependent kernel launches, not the throughput figure"}
+                    "note": "batch of 1: 15 dependent kernel launches, not the throughput figure"}
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1) --------
     cpu = None
