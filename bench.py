@@ -60,6 +60,7 @@ def main() -> None:
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--cpu-sample-pairs", type=int, default=16, help="1080p pairs the CPU oracle is timed on (~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-pair", action="store_true", help="skip the informational batch-of-1 timing")
     args = ap.parse_args()
 
     import numpy as np
@@ -168,7 +169,7 @@ def main() -> None:
 
     # ---- one pair per call (BASELINE config 3 read literally): latency-bound, informational ----
     one_pair = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_one_pair:
         plan1 = _oflk.Plan(local_rank, 1, H, W, L, args.window, K)
         for _ in range(5):
             plan1.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
