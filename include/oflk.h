@@ -147,7 +147,7 @@ int oflk_plan_read_log(oflk_plan *plan, float *residual_log, int *iters_run, voi
  *   launches  : launch count per class
  * Returns the number of classes written (>= 0) or an error code.
  * enabled: 0 off, 1 every kernel, 2 only the dominant kernel (fused LK iteration at the
- * finest level; three event pairs per pyramidal call instead of ~30). */
+ * finest level; three event pairs per pyramidal call instead of 15). */
 int oflk_plan_set_profiling(oflk_plan *plan, int enabled);
 int oflk_plan_kernel_times(oflk_plan *plan, const char **names, double *total_ms, long *launches,
                            int max_entries);

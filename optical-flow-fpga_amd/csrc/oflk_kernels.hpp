@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         if (MODE == MODE_ITER) {
             // |d| sums of the tile: six fp32 terms per thread, a fixed-order wave reduction
             // (DPP adds, total in lane 63), then fp64 across the four waves.  The reference's
-            // np.mean is itself an fp32 pairwise sum; see k_finalize.
+            // np.mean is itself an fp32 pairwise sum; see lk_report / lk_level_state.
             su = wave_sum_to_lane63(su);
             sv = wave_sum_to_lane63(sv);
             if ((tid & 63) == 63) {
