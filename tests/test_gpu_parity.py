@@ -294,6 +294,37 @@ def test_bench_workload_batch_equals_single_pair_calls(P):
         np.testing.assert_allclose(log[i], slog, rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("shape", [(203, 317), (130, 332), (75, 1283)])
+def test_chained_tiles_on_ragged_shapes(oracle, shape):
+    """many small pairs in one call: the launch is large enough for the chained-tile path while the
+    frames end in partial tiles on both axes (odd widths take the scalar load/store paths).  Every
+    pair must equal the oracle's result for it."""
+    import ctypes
+
+    import _oflk
+
+    H, W = shape
+    L, K, B = 3, 2, 256
+    rng = np.random.default_rng(H * 1000 + W)
+    distinct = [_rand_pair(rng, H, W) for _ in range(3)]
+    distinct.append((distinct[0][0], distinct[0][0].copy()))   # one pair that converges at once
+    expect = [oracle.lucas_kanade_pyramidal_ex(a, b, L, 5, K) for a, b in distinct]
+    prev = np.stack([distinct[i % 4][0] for i in range(B)])
+    curr = np.stack([distinct[i % 4][1] for i in range(B)])
+    u = np.empty_like(prev)
+    v = np.empty_like(prev)
+    runs = np.zeros((B, L), np.int32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    _oflk.check(_oflk.lib().oflk_pyramidal_batch(prev.ctypes.data_as(f32p), curr.ctypes.data_as(f32p), B, H, W, L, 5, K,
+                                                 u.ctypes.data_as(f32p), v.ctypes.data_as(f32p), None,
+                                                 runs.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+    for i in range(B):
+        eu, ev, _, eruns = expect[i % 4]
+        assert list(runs[i]) == list(eruns), i
+        _eq(u[i], eu, f"u of pair {i}")
+        _eq(v[i], ev, f"v of pair {i}")
+
+
 def test_640x480_single_scale_matches_oracle(K, oracle):
     """configs[1]"""
     from oflk_synth import synth_pair
