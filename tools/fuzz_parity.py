@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Randomised differential run: HIP path vs the CPU oracle on random shapes, parameters and data
+(development tool, run on the GPU box; the committed test-suite holds the fixed cases).
+Usage: python3 tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "optical-flow-fpga_amd" / "python"))
+sys.path.insert(0, str(ROOT / "oracle"))
+os.environ.setdefault("OFLK_QUIET", "1")
+
+import lucas_kanade_core as K  # noqa: E402
+import lucas_kanade_pyramidal as P  # noqa: E402
+import oflk_oracle as O  # noqa: E402
+
+
+def same(a, b):
+    return np.array_equal(a, b)   # -0.0 == +0.0, NaN never produced from finite inputs
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for i in range(cases):
+        H = int(rng.integers(1, 220))
+        W = int(rng.integers(1, 300))
+        win = int(rng.choice([3, 4, 5, 5, 5, 7, 9, 11]))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:      # 8-bit frames
+            a = rng.integers(0, 256, (H, W)).astype(np.float32)
+            b = np.roll(a, int(rng.integers(-3, 4)), axis=1)
+        elif kind == 1:    # smooth texture + noise
+            yy, xx = np.mgrid[0:H, 0:W]
+            a = (128 + 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + rng.normal(0, 4, (H, W))).astype(np.float32)
+            b = (128 + 60 * np.sin((xx - 1.7) / 7.0) * np.cos((yy + 0.6) / 5.0) + rng.normal(0, 4, (H, W))).astype(np.float32)
+        elif kind == 2:    # signed, wide dynamic range
+            a = (rng.normal(0, 1, (H, W)) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+            b = (a + rng.normal(0, 0.1, (H, W)) * 10.0 ** rng.integers(-3, 3)).astype(np.float32)
+        else:              # mostly flat with a few features
+            a = np.full((H, W), 77.0, np.float32)
+            for _ in range(5):
+                y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+                a[max(y - 3, 0):y + 4, max(x - 3, 0):x + 4] += rng.normal(0, 30, a[max(y - 3, 0):y + 4, max(x - 3, 0):x + 4].shape).astype(np.float32)
+            b = np.roll(a, 1, axis=0)
+        ok = True
+        u, v = K.lucas_kanade_single_scale(a, b, win)
+        ou, ov = O.lucas_kanade_single_scale(a, b, win)
+        ok &= same(u, ou) and same(v, ov)
+        L = int(rng.integers(1, 5))
+        it = int(rng.integers(0, 4))
+        while L > 1 and (int(H * 0.5 ** (L - 1)) < 1 or int(W * 0.5 ** (L - 1)) < 1):
+            L -= 1
+        gu, gv, glog, gruns = P.lucas_kanade_pyramidal_with_log(a, b, L, win, it)
+        eu, ev, elog, eruns = O.lucas_kanade_pyramidal_ex(a, b, L, win, it)
+        ok &= list(gruns[:L]) == list(eruns) and same(gu, eu) and same(gv, ev)
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {i}: H={H} W={W} win={win} kind={kind} L={L} iters={it} runs gpu={list(gruns[:L])} oracle={list(eruns)}", flush=True)
+        if i % 50 == 49:
+            print(f"{i + 1} cases, {bad} mismatches", flush=True)
+    print(f"done: {cases} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
