@@ -28,8 +28,8 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0
     for i in range(cases):
-        H = int(rng.integers(1, 220))
-        W = int(rng.integers(1, 300))
+        H = int(rng.integers(1, int(os.environ.get("FUZZ_MAXH", 220))))
+        W = int(rng.integers(1, int(os.environ.get("FUZZ_MAXW", 300))))
         win = int(rng.choice([3, 4, 5, 5, 5, 7, 9, 11]))
         kind = int(rng.integers(0, 4))
         if kind == 0:      # 8-bit frames
