@@ -22,7 +22,48 @@ def same(a, b):
     return np.array_equal(a, b)   # -0.0 == +0.0, NaN never produced from finite inputs
 
 
+def batch_main(cases, seed):
+    """large launches (many small pairs per call): the chained-tile / strip-per-XCD path"""
+    import ctypes
+
+    import _oflk
+
+    rng = np.random.default_rng(seed)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    bad = 0
+    for i in range(cases):
+        H, W = int(rng.integers(30, 260)), int(rng.integers(30, 400))
+        B = int(rng.integers(40, 520))
+        L, K = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        win = int(rng.choice([3, 5, 5, 5, 7]))
+        distinct = []
+        for _ in range(3):
+            a = rng.normal(110, 45, (H, W)).astype(np.float32)
+            distinct.append((a, (a + rng.normal(0, 6, (H, W))).astype(np.float32)))
+        distinct.append((distinct[0][0], distinct[0][0].copy()))
+        expect = [O.lucas_kanade_pyramidal_ex(a, b, L, win, K) for a, b in distinct]
+        order = rng.integers(0, 4, B)
+        prev = np.stack([distinct[k][0] for k in order])
+        curr = np.stack([distinct[k][1] for k in order])
+        u, v = np.empty_like(prev), np.empty_like(prev)
+        runs = np.zeros((B, L), np.int32)
+        _oflk.check(_oflk.lib().oflk_pyramidal_batch(prev.ctypes.data_as(f32p), curr.ctypes.data_as(f32p), B, H, W, L, win,
+                                                     K, u.ctypes.data_as(f32p), v.ctypes.data_as(f32p), None,
+                                                     runs.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        ok = all(same(u[j], expect[k][0]) and same(v[j], expect[k][1]) and list(runs[j]) == list(expect[k][3])
+                 for j, k in enumerate(order))
+        if not ok:
+            bad += 1
+            print(f"MISMATCH batch case {i}: B={B} H={H} W={W} L={L} K={K} win={win}", flush=True)
+        if i % 10 == 9:
+            print(f"{i + 1} batch cases, {bad} mismatches", flush=True)
+    print(f"done: {cases} batch cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "batch":
+        return batch_main(int(sys.argv[2]) if len(sys.argv) > 2 else 30, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
