@@ -307,7 +307,7 @@ struct LkArgs {
 #define OFLK_NY 3      // output rows per thread: tile = 64 x 8*NY
 #endif
 #ifndef OFLK_BATCH
-#define OFLK_BATCH 4   // warp cells whose gathers are in flight together (ITER stage 1)
+#define OFLK_BATCH 5   // warp cells whose gathers are in flight together (ITER stage 1)
 #endif
 // XCD-aware tile order (speed only, never correctness).  Workgroups of a 1-D grid are
 // dealt round-robin over the 8 XCDs (ids i and i+8 share an XCD, each with its own L2).
