@@ -307,7 +307,7 @@ struct LkArgs {
 #define OFLK_NY 3      // output rows per thread: tile = 64 x 8*NY
 #endif
 #ifndef OFLK_BATCH
-#define OFLK_BATCH 5   // warp cells whose gathers are in flight together (ITER stage 1)
+#define OFLK_BATCH 5   // warp cells whose gathers are in flight together (ITER stage 1, 5x5 window)
 #endif
 // XCD-aware tile order (speed only, never correctness).  Workgroups of a 1-D grid are
 // dealt round-robin over the 8 XCDs (ids i and i+8 share an XCD, each with its own L2).
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                     // advance by (QS, RS) with carry at AW columns, which avoids a division per cell.
                     constexpr int AW = k5TX + 2 * R;                 // cells per row (x0-R ..)
                     constexpr int NE = (AH * AW + 255) / 256;        // cells per thread (full tile)
-                    constexpr int BATCH = OFLK_BATCH;
+                    constexpr int BATCH = HW == 2 ? OFLK_BATCH : 4;   // 3x3: one register too many at 5
                     constexpr int QS = 256 / AW, RS = 256 % AW;      // row / column advance per 256 cells
                     constexpr int SC = SX - R;                       // staging column of cell column 0
                     constexpr int ncells = (AH - rstart) * AW;
@@ -838,8 +838,14 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                     }
                 }
             };
+#ifdef OFLK_SETPRIO
+            if (MODE == MODE_ITER) __builtin_amdgcn_s_setprio(OFLK_SETPRIO);   // the latency chain of a tile
+#endif
             if (rstart == 0) stage1(std::integral_constant<int, 0>{});
             else stage1(std::integral_constant<int, 2 * R>{});
+#ifdef OFLK_SETPRIO
+            if (MODE == MODE_ITER) __builtin_amdgcn_s_setprio(0);
+#endif
             __syncthreads();
             // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
 #pragma unroll
@@ -957,6 +963,19 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         unsigned ofs = ((unsigned)__mul24(gyb, W) + (unsigned)gxb) * 4u;
         const unsigned rowbytes = 4u * (unsigned)W;
         const bool pairs = VEC || (W & 1) == 0;   // gxb is even: an aligned float2 inside the row
+        // flow += d (lucas_kanade_pyramidal.py:209-210): the current flow of all the thread's rows is
+        // requested before the first solve, so the divisions run under the loads' latency
+        // (only where the registers are there: 5x5 window, width a multiple of 4)
+        constexpr bool PRELOAD = MODE == MODE_ITER && HW == 2 && VEC;
+        float2 pu[NY], pv[NY];
+        if (PRELOAD) {
+#pragma unroll
+            for (int oy = 0; oy < NY; oy++) {
+                const bool in = gyb + oy < H && gxb < W;
+                pu[oy] = in ? ld_off<float2>(iu, ofs + oy * rowbytes) : make_float2(0.0f, 0.0f);
+                pv[oy] = in ? ld_off<float2>(iv, ofs + oy * rowbytes) : make_float2(0.0f, 0.0f);
+            }
+        }
 #pragma unroll
         for (int oy = 0; oy < NY; oy++, ofs += rowbytes) {
             const int gy = gyb + oy;
@@ -979,11 +998,12 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                     float2 ru = make_float2(du[0], du[1]);
                     float2 rv = make_float2(dv[0], dv[1]);
                     if (MODE == MODE_ITER) {
-                        // flow += d (lucas_kanade_pyramidal.py:209-210)
-                        const float2 pu = ld_off<float2>(iu, ofs);
-                        const float2 pv = ld_off<float2>(iv, ofs);
-                        ru.x = pu.x + ru.x; ru.y = pu.y + ru.y;
-                        rv.x = pv.x + rv.x; rv.y = pv.y + rv.y;
+                        if (!PRELOAD) {
+                            pu[oy] = ld_off<float2>(iu, ofs);
+                            pv[oy] = ld_off<float2>(iv, ofs);
+                        }
+                        ru.x = pu[oy].x + ru.x; ru.y = pu[oy].y + ru.y;
+                        rv.x = pv[oy].x + rv.x; rv.y = pv[oy].y + rv.y;
                     }
                     st_off<float2>(ou, ofs, ru);
                     st_off<float2>(ov, ofs, rv);
