@@ -838,14 +838,8 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                     }
                 }
             };
-#ifdef OFLK_SETPRIO
-            if (MODE == MODE_ITER) __builtin_amdgcn_s_setprio(OFLK_SETPRIO);   // the latency chain of a tile
-#endif
             if (rstart == 0) stage1(std::integral_constant<int, 0>{});
             else stage1(std::integral_constant<int, 2 * R>{});
-#ifdef OFLK_SETPRIO
-            if (MODE == MODE_ITER) __builtin_amdgcn_s_setprio(0);
-#endif
             __syncthreads();
             // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
 #pragma unroll
