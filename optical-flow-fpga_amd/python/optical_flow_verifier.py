@@ -24,7 +24,7 @@ import numpy as np
 import numpy.typing as npt
 import yaml
 
-from flow_metrics import compute_all_metrics
+from flow_metrics import compute_all_metrics, compute_all_metrics_gpu
 from lucas_kanade_core import lucas_kanade_single_scale
 from lucas_kanade_pyramidal import lucas_kanade_pyramidal
 
@@ -99,8 +99,11 @@ def classify_result(mae_u: float, mae_v: float, pattern_type: str, config: Dict[
 
 
 def verify_pattern(pattern_name: str, pattern_data: Dict[str, Any], config: Dict[str, Any],
-                   pyramid_config_name: str = "default", verbose: bool = True) -> Dict[str, Any]:
-    """Both LK variants on one pattern, metrics vs the constant ground truth (reference :211-312)."""
+                   pyramid_config_name: str = "default", verbose: bool = True,
+                   device_metrics: bool = False) -> Dict[str, Any]:
+    """Both LK variants on one pattern, metrics vs the constant ground truth (reference :211-312).
+    device_metrics=True reduces the masked metrics on the GPU (oflk_flow_metrics) instead of in NumPy;
+    the numbers agree to ~1e-6 relative, so the default keeps the reference's own arithmetic."""
     say = print if verbose else (lambda *a, **k: None)
     prev, curr, meta = pattern_data["frame_prev"], pattern_data["frame_curr"], pattern_data["metadata"]
     motion = meta["motion_parameters"]
@@ -121,7 +124,7 @@ def verify_pattern(pattern_name: str, pattern_data: Dict[str, Any], config: Dict
     for key, label, fn in runs:
         say(f"\nRunning {label}...")
         u, v = fn()
-        m = compute_all_metrics(u, v, u_true, v_true, mask)
+        m = (compute_all_metrics_gpu if device_metrics else compute_all_metrics)(u, v, u_true, v_true, mask)
         say(f"  MAE: u={m['mae_u']:.3f}, v={m['mae_v']:.3f}\n  RMSE: {m['rmse']:.3f}\n  EPE: {m['epe']:.3f}\n"
             f"  AAE: {m['aae']:.2f}°")
         out[key] = {"metrics": m, "status": classify_result(m["mae_u"], m["mae_v"], pattern_name, config)}
@@ -316,6 +319,8 @@ def main() -> None:
     ap.add_argument("--compare-baseline", action="store_true")
     ap.add_argument("--update-baseline", action="store_true")
     ap.add_argument("--regression-threshold", type=float, default=10.0)
+    ap.add_argument("--device-metrics", action="store_true",
+                    help="reduce MAE/RMSE/EPE/AAE on the GPU (not a reference option; ~1e-6 relative to the host values)")
     args = ap.parse_args()
 
     config_path = Path(args.config)
@@ -343,7 +348,8 @@ def main() -> None:
     results = []
     for name in names:
         data = load_test_pattern(suite_dir / name)
-        results.append(verify_pattern(name, data, config, pyramid_config_name=args.pyramid_config, verbose=True))
+        results.append(verify_pattern(name, data, config, pyramid_config_name=args.pyramid_config, verbose=True,
+                                      device_metrics=args.device_metrics))
         if not args.no_visualizations and name in config["visualization"]["showcase_patterns"]:
             single = run_single_scale_lk(data["frame_prev"], data["frame_curr"],
                                          config["pyramids"]["default"]["window_size"])

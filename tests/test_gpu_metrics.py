@@ -141,3 +141,24 @@ def test_plan_metrics_on_device_resident_batch():
     for b in range(B):
         eu, ev = P.lucas_kanade_pyramidal(pairs[b][0], pairs[b][1], 3, 5, 3)
         assert np.array_equal(hu[b], eu) and np.array_equal(hv[b], ev)
+
+
+def test_verifier_with_device_metrics_keeps_every_status(golden_dir):
+    """optical_flow_verifier.verify_pattern(device_metrics=True): same Pass/Warning/Fail classification and
+    metrics within 2e-5 of the reference's baseline on all 13 patterns"""
+    import generate_test_suite as G
+    import optical_flow_verifier as V
+    from conftest import PRODUCT
+
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    base = json.loads((golden_dir / "verification_baseline.json").read_text())["patterns"]
+    cfg = V.load_config(PRODUCT / "verification_config.yaml")
+    p = z["frame_0"].astype(np.float32)
+    for name, params in G.TEST_PATTERNS.items():
+        data = {"frame_prev": p, "frame_curr": z[f"frame_1__{name}"].astype(np.float32),
+                "metadata": {"motion_parameters": params.to_dict()}}
+        r = V.verify_pattern(name, data, cfg, verbose=False, device_metrics=True)
+        for key in ("single_scale", "pyramidal"):
+            assert r[key]["status"] == base[name][key]["status"], (name, key)
+            for k, val in base[name][key]["metrics"].items():
+                assert abs(r[key]["metrics"][k] - val) <= 2e-5, (name, key, k)
