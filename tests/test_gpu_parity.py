@@ -248,6 +248,22 @@ def test_errors_are_loud():
         K_.lucas_kanade_single_scale(a, np.zeros((8, 9), np.float32))
     with pytest.raises(_oflk.OflkError):
         K_.lucas_kanade_single_scale(a, a, 13)  # window not built -> explicit error, no fallback
+    # C ABI argument checks: status code + message, never a crash
+    import ctypes
+
+    L = _oflk.lib()
+    f32p = ctypes.POINTER(ctypes.c_float)
+    none = ctypes.cast(None, f32p)
+    assert L.oflk_single_scale(none, _oflk.ptr(a), 8, 8, 5, _oflk.ptr(a), _oflk.ptr(a)) == _oflk.OFLK_ERR_INVALID
+    assert b"NULL" in L.oflk_last_error()
+    assert L.oflk_pyramidal(_oflk.ptr(a), _oflk.ptr(a), 8, 8, 0, 5, 3, _oflk.ptr(a), _oflk.ptr(a), None, None) == _oflk.OFLK_ERR_INVALID
+    assert L.oflk_pyramidal(_oflk.ptr(a), _oflk.ptr(a), 8, 8, 5, 5, 3, _oflk.ptr(a), _oflk.ptr(a), None, None) == _oflk.OFLK_ERR_INVALID  # level 4 would be empty
+    out = (ctypes.c_double * 5)()
+    t = np.zeros(1, np.float32)
+    assert L.oflk_flow_metrics(_oflk.ptr(a), _oflk.ptr(a), 0, 8, 8, _oflk.ptr(t), _oflk.ptr(t), 0, 8, 0, 8, out) == _oflk.OFLK_ERR_INVALID
+    h = ctypes.c_void_p()
+    assert L.oflk_plan_create(ctypes.byref(h), 0, 1, 1 << 16, 1 << 16, 1, 5, 0) == _oflk.OFLK_ERR_UNSUPPORTED  # >= 2^30 pixels
+    assert L.oflk_plan_create(ctypes.byref(h), 99, 1, 8, 8, 1, 5, 0) != _oflk.OFLK_OK   # no such device
 
 
 # ---- BASELINE.json full sizes ---------------------------------------------------
