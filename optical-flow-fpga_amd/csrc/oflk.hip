@@ -248,7 +248,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     Prof pr(plan, s, cls);
     // 1-D grid.  Large launches chain vertically adjacent tiles in one block (they share 2R
     // staging rows, the expensive part of stage 1): tile rows are cut into segments of `cap`
-    // rows, then ever shorter ones, and every XCD runs its segments longest first so that the
+    // rows, then ever shorter ones (each at most half of what is left), and every XCD runs its segments longest first so that the
     // drain of the grid is made of single tiles.  Small launches keep one tile per block.
     const int tiles_x = (a.W + k5TX - 1) / k5TX, tiles_y = (a.H + k5TY - 1) / k5TY;
     if (a.W <= 2 * hw || a.H <= 2 * hw) {
@@ -272,7 +272,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         int row = 0, n = 0;
         while (row < tiles_y) {
             const int rest = tiles_y - row;
-            int len = std::min(cap, std::max(1, rest / 3));
+            int len = std::min(cap, std::max(1, rest / 2));   // halving tail: 8,8,8,8,6,3,2,1,1 for 45 rows
             if (n == kMaxSegs - 1) len = rest;  // cannot happen for cap chosen above; stay in bounds
             a.seg_row[n++] = (unsigned short)row;
             row += len;
