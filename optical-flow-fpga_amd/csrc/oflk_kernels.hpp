@@ -1401,31 +1401,37 @@ __global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
     const int j0 = jb + (tid & 63) * 4;
     const int i = ib + (tid >> 6);
     if (j0 >= a.Wo || i >= a.Ho) return;
+    // Same sampling as lean_taps (see there): one unsigned compare per axis for the range test,
+    // and a sample exactly on the last index is expressed from the cell before it (floor capped at
+    // N-2, fraction exactly 1), so the two taps of an axis are always adjacent cells of the staged
+    // tile.  The y side is per thread, the x side per output, the tap arithmetic per plane.
+    const LeanGeom lg = lean_geom(H, W);
     const double y = linspace_at(a.ly, i);
-    const bool y_in = !(y < 0.0 || y > (double)(H - 1));
-    const double fy = floor(y);
-    const int y0 = min(max((int)fy, 0), H - 1);
+    const bool y_in = (unsigned long long)__double_as_longlong(y) <= (unsigned long long)__double_as_longlong(lg.Hm1);
+    const double fy = fmin(floor(y), lg.Hm2);
     const double wy0 = 1.0 - (y - fy), wy1 = 1.0 - wy0;
-    const int y1 = (y0 + 1 < H) ? y0 + 1 : (H > 1 ? H - 2 : 0);
+    const int row0 = y_in ? (int)fy - ylo : 0;
+    const int rstep = H > 1 ? kUSW : 0;           // LDS words from tap row 0 to tap row 1
+    const int cstep = W > 1 ? 1 : 0;
+    const float *__restrict__ tile = &s_src[0][0][0];
     float res[2][4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = min(j0 + k, a.Wo - 1);
         const double x = linspace_at(a.lx, j);
-        const bool inside = y_in && !(x < 0.0 || x > (double)(W - 1));
-        const double fx = floor(x);
-        const int x0 = min(max((int)fx, 0), W - 1);
+        const bool inside =
+            y_in & ((unsigned long long)__double_as_longlong(x) <= (unsigned long long)__double_as_longlong(lg.Wm1));
+        const double fx = fmin(floor(x), lg.Wm2);
         const double wx0 = 1.0 - (x - fx), wx1 = 1.0 - wx0;
-        const int x1 = (x0 + 1 < W) ? x0 + 1 : (W > 1 ? W - 2 : 0);
+        const int o00 = inside ? row0 * kUSW + ((int)fx - xlo) : 0;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            const float *r0 = &s_src[p][y0 - ylo][0] - xlo;
-            const float *r1 = &s_src[p][y1 - ylo][0] - xlo;
-            double acc = 0.0, c;
-            c = (double)r0[x0]; c = c * wy0; c = c * wx0; acc = acc + c;
-            c = (double)r0[x1]; c = c * wy0; c = c * wx1; acc = acc + c;
-            c = (double)r1[x0]; c = c * wy1; c = c * wx0; acc = acc + c;
-            c = (double)r1[x1]; c = c * wy1; c = c * wx1; acc = acc + c;
+            const float *t = tile + p * (kUSH * kUSW) + o00;
+            double acc, c;
+            c = (double)t[0]; c = c * wy0; acc = c * wx0;
+            c = (double)t[cstep]; c = c * wy0; c = c * wx1; acc = acc + c;
+            c = (double)t[rstep]; c = c * wy1; c = c * wx0; acc = acc + c;
+            c = (double)t[rstep + cstep]; c = c * wy1; c = c * wx1; acc = acc + c;
             float r = inside ? (float)acc : 0.0f;
             res[p][k] = r * a.scale[p];   // fp32 multiply by float32(scale), :135-136
         }
