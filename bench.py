@@ -131,6 +131,13 @@ def main() -> None:
     plan.set_profiling(0)
     log, runs = plan.read_log(stream)
 
+    # job-wide result summary: one small SUM all-reduce (RCCL) of per-rank totals, outside the timed region
+    tot_u = group.sum_over_ranks(float(u.abs().sum(dtype=torch.float64).item()))
+    tot_v = group.sum_over_ranks(float(v.abs().sum(dtype=torch.float64).item()))
+    tot_pairs = int(round(group.sum_over_ranks(float(B))))
+    job_stats = {"pairs_per_step": tot_pairs, "mean_abs_u": round(tot_u / (tot_pairs * H * W), 6),
+                 "mean_abs_v": round(tot_v / (tot_pairs * H * W), 6)}
+
     total_pix = float(world) * B * H * W * args.steps
     value = total_pix / elapsed / 1e6
 
@@ -231,6 +238,7 @@ def main() -> None:
             "roofline": roofline,
             "whole_call": whole,
             "kernels": kernels,
+            "job_stats": job_stats,
             "one_pair_per_call": one_pair,
             "cpu_baseline": cpu,
         }
