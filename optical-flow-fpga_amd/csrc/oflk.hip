@@ -176,6 +176,10 @@ struct oflk_plan {
     //   acc[B][L][K][kAccShards][kAccStride] (u64) | iters_run[B][L] (i32) | log[B][L][K][2] (f32)
     unsigned long long *state = nullptr;
     GaussW gauss;
+#ifdef OFLK_STAMPS
+    unsigned *stamps = nullptr;      // diagnostic build: per-wave section cycle sums of the last finest-level launch
+    size_t stamps_blocks = 0;
+#endif
     // profiling
     bool prof = false;
     int prof_only = -1;  // >= 0: bracket only launches of this kernel class
@@ -283,6 +287,19 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         nblocks = 8u * (unsigned)((strips + 7) / 8) * (unsigned)n;
     }
     dim3 grid(nblocks);
+#ifdef OFLK_STAMPS
+    a.stamps = nullptr;
+    if (plan && cls == KC_LK_ITER_FINEST) {
+        if (plan->stamps_blocks < nblocks) {
+            if (plan->stamps) (void)hipFree(plan->stamps);
+            plan->stamps = nullptr;
+            HIP_TRY(hipMalloc((void **)&plan->stamps, (size_t)nblocks * 512 * sizeof(unsigned)));
+            plan->stamps_blocks = nblocks;
+        }
+        HIP_TRY(hipMemsetAsync(plan->stamps, 0, (size_t)nblocks * 512 * sizeof(unsigned), s));
+        a.stamps = plan->stamps;
+    }
+#endif
     const bool vec = (a.W & 3) == 0;
 #define OFLK_LAUNCH_LKW(HWV)                                                          \
     do {                                                                              \
@@ -472,6 +489,9 @@ void plan_free(oflk_plan *p)
     if (p->tmpA) (void)hipFree(p->tmpA);
     if (p->tmpB) (void)hipFree(p->tmpB);
     if (p->state) (void)hipFree(p->state);
+#ifdef OFLK_STAMPS
+    if (p->stamps) (void)hipFree(p->stamps);
+#endif
     for (auto &e : p->pending) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -720,6 +740,20 @@ OFLK_API int oflk_plan_read_log(oflk_plan *p, float *residual_log, int *iters_ru
     HIP_TRY(hipStreamSynchronize(s));
     return OFLK_OK;
 }
+
+#ifdef OFLK_STAMPS
+// diagnostic build only (tools/stamps.py): [blocks][4 waves][8 tiles][16] s_memtime stamps of the last
+// finest-level iteration launch; returns the number of blocks
+OFLK_API long oflk_debug_stamps(oflk_plan *p, unsigned *out, long max_blocks)
+{
+    if (!p || !p->stamps) return 0;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    const long n = std::min<long>((long)p->stamps_blocks, max_blocks);
+    if (out && hipMemcpy(out, p->stamps, (size_t)n * 512 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)p->stamps_blocks;
+}
+#endif
 
 OFLK_API int oflk_plan_set_profiling(oflk_plan *p, int enabled)
 {

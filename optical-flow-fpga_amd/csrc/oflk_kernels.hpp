@@ -18,6 +18,18 @@
 
 #pragma clang fp contract(off)
 
+// timing experiments only (tools/ablate.sh): bit 0 no solve, 1 no window adds (LDS reads kept),
+// 2 no window LDS reads either, 3 no fp64 warp arithmetic, 4 no Sobel arithmetic.  Results are wrong.
+#ifndef OFLK_ABLATE
+#define OFLK_ABLATE 0
+#endif
+#ifndef OFLK_G
+#define OFLK_G 14
+#endif
+#ifndef OFLK_L2_PREFETCH
+#define OFLK_L2_PREFETCH 0
+#endif
+
 namespace oflk {
 
 constexpr int kMaxRadius = 64;
@@ -166,6 +178,13 @@ __device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v)
 __device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx, float u, float v)
 {
     LeanTaps t;
+    if constexpr ((OFLK_ABLATE & 8) != 0) {
+        const int yy = gy + (int)v, xx = gx + (int)u;
+        t.inside = (unsigned)yy < (unsigned)(int)g.Hm1 && (unsigned)xx < (unsigned)(int)g.Wm1;
+        t.off0 = t.inside ? ((unsigned)__mul24(yy, g.W) + (unsigned)xx) * 4u : 0u;
+        t.wy0 = t.wy1 = t.wx0 = t.wx1 = 0.0;
+        return t;
+    }
     const double y = (double)gy + (double)v;   // int64 + float32 -> float64, as the reference
     const double x = (double)gx + (double)u;
     // 0 <= y <= H-1 as ONE unsigned compare of the bit patterns: non-negative doubles order like
@@ -204,6 +223,7 @@ __device__ __forceinline__ float lean_finish(const LeanTaps &t, PairF r0, PairF 
 {
     // SciPy starts the sum at +0.0; adding the first term to it only matters for the sign of an
     // all-zero result (-0.0 vs +0.0, equal as values), so the sum starts at the first term
+    if constexpr ((OFLK_ABLATE & 8) != 0) return t.inside ? r0.a + r0.b + r1.a + r1.b : 0.0f;
     double acc, c;
     c = (double)r0.a; c = c * t.wy0; acc = c * t.wx0;
     c = (double)r0.b; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
@@ -230,6 +250,11 @@ __device__ __forceinline__ double linspace_at(const Linspace &l, int i)
 __device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float Sxt, float Syt,
                                          float &u, float &v)
 {
+    if constexpr ((OFLK_ABLATE & 1) != 0) {
+        u = Sxx + Sxt;
+        v = Syy + Syt + Sxy;
+        return;
+    }
     float b0 = -Sxt, b1 = -Syt;
     float m0 = Sxx * Syy;
     float m1 = Sxy * Sxy;
@@ -278,6 +303,9 @@ struct LkArgs {
     // block; nseg = 0 means one tile per block (plain XCD tile order)
     int nseg;
     unsigned short seg_row[kMaxSegs + 1];
+#ifdef OFLK_STAMPS
+    unsigned *stamps;   // diagnostic build only: [block][wave][16] cycle sums per code section
+#endif
 };
 
 // ---------------------------------------------------------------------------
@@ -359,7 +387,31 @@ __device__ __forceinline__ void pin(float2 &x)
     x = __builtin_bit_cast(float2, d);
 }
 
+// Two planes summed side by side.  OFLK_PK_SUMS = 1 adds them with one v_pk_add_f32 (float2);
+// 0 (default) with two v_add_f32: on gfx950 a packed fp32 add occupies the vector ALU 2.7x as long
+// as a scalar one (tools/ubench/valu_cycles.hip), so two scalar adds are the cheaper pair.
+#ifndef OFLK_PK_SUMS
+#define OFLK_PK_SUMS 0
+#endif
+struct F2 {
+    float x, y;
+};
+__device__ __forceinline__ F2 operator+(F2 a, F2 b) { return F2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ void pin(F2 &v)
+{
+    asm volatile("" : "+v"(v.x));
+    asm volatile("" : "+v"(v.y));
+}
+#if OFLK_PK_SUMS
+using Sum2 = float2;
+__device__ __forceinline__ Sum2 sum2(float a, float b) { return make_float2(a, b); }
+#else
+using Sum2 = F2;
+__device__ __forceinline__ Sum2 sum2(float a, float b) { return F2{a, b}; }
+#endif
+
 template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ F2 zero_of<F2>() { return F2{0.0f, 0.0f}; }
 template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
 template <> __device__ __forceinline__ float2 zero_of<float2>() { return make_float2(0.0f, 0.0f); }
 
@@ -369,6 +421,24 @@ template <> __device__ __forceinline__ float2 zero_of<float2>() { return make_fl
 template <typename T, int NY, typename LoadRow>
 __device__ __forceinline__ void patch5_sums(LoadRow load_row, T (&out)[NY][2])
 {
+    if constexpr ((OFLK_ABLATE & 6) != 0) {
+        T acc[2] = {zero_of<T>(), zero_of<T>()};
+#pragma unroll
+        for (int i = 0; i < ((OFLK_ABLATE & 4) ? 1 : NY + 4); i++) {
+            T w[6];
+            load_row(i, w);
+#pragma unroll
+            for (int c = 0; c < 6; c++) pin(w[c]);
+            acc[0] = w[2];
+            acc[1] = w[3];
+        }
+#pragma unroll
+        for (int oy = 0; oy < NY; oy++) {
+            out[oy][0] = acc[0];
+            out[oy][1] = acc[1];
+        }
+        return;
+    }
     T R0[NY + 1][3], R2[NY + 1][3], R4[NY][2];
     T w[NY + 4][6];
     load_row(0, w[0]);
@@ -598,8 +668,29 @@ __global__ __launch_bounds__(256) void k_lk_degenerate(LkArgs a)
 template <int HW, int MODE>
 constexpr bool kLkChain = HW <= 2 && MODE != MODE_GRADS;
 
+// In-kernel timeline (diagnostic build -DOFLK_STAMPS only; tools/stamps.py): every wave keeps the
+// s_memtime value of each stamp of each of its (up to 8) tiles in LDS and copies them out once.
+// The values go to a buffer of their own; no output is computed from them.
+#ifdef OFLK_STAMPS
+#ifndef OFLK_STAMP_MASK
+#define OFLK_STAMP_MASK 0xffff
+#endif
+#define OFLK_STAMP(i)                                                                              \
+    if ((OFLK_STAMP_MASK >> (i)) & 1) do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        s_st[st_wave][st_tile & 7][i] = (unsigned)t_;                                              \
+    } while (0)
+#define OFLK_STAMP_OCC
+#else
+#define OFLK_STAMP(i) do { } while (0)
+#define OFLK_STAMP_OCC
+#endif
+
 template <int HW, int MODE, bool VEC>
-__global__ __launch_bounds__(256) void k_lkw(LkArgs a)
+__global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
 {
     static_assert(HW >= 1 && HW <= 5, "windows up to 11x11 (NumPy's single pairwise block)");
     constexpr int R = HW + 1;                              // halo of the frame-average tile
@@ -669,6 +760,13 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     const int x0 = tile_x * k5TX;
     float carry_a[NC], carry_i[NC];
     double blk_u = 0.0, blk_v = 0.0;   // thread 0: |d| sums of the block's tiles
+#ifdef OFLK_STAMPS
+    __shared__ unsigned s_st[4][8][16];
+    const int st_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int st_tile = 0;
+    for (int i = threadIdx.x; i < 4 * 8 * 16; i += 256) (&s_st[0][0][0])[i] = 0u;
+    __syncthreads();
+#endif
 
     for (int it = 0; it < (CHAIN ? ntile : 1); it++) {
         // re-derived per tile behind an opaque move: otherwise every per-thread address of all
@@ -678,6 +776,10 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         const int tile_y = tile_y_first + it;
         const int y0 = tile_y * k5TY;
         const int rstart = (!CHAIN || it == 0) ? 0 : 2 * R;  // first staging row to compute
+#ifdef OFLK_STAMPS
+        st_tile = it;
+#endif
+        OFLK_STAMP(0);   // [0] top of the tile
 
         float gix[NG], giy[NG], git[NG];
         if (MODE == MODE_GRADS) {
@@ -700,7 +802,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
                     int qi = tid + j * 256;
-                    if (qi < NCARRY) {
+                    if (((OFLK_G & 1) && (j + 1) * 256 <= NCARRY) || qi < NCARRY) {   // only the last j is partial: no mask juggling for the others
                         s_avg[qi] = carry_a[j];
                         s_it[qi] = carry_i[j];
                     }
@@ -733,7 +835,8 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     #pragma unroll
                         for (int k = 0; k < NE; k++) {
                             if (k * 256 < ncells) {  // uniform: cell k exists for some thread
-                                int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);  // "symm" ring; farther cells are never used
+                                const int rr = ((OFLK_G & 4) && (k + 1) * 256 <= ncells) ? r : min(r, AH - 1);   // only the last k runs past the tile
+                                int gy = clamp0(y0 - R + rr, Hm1);  // "symm" ring; farther cells are never used
                                 int gx = clamp0(x0 - R + c, Wm1);
                                 unsigned i = ((unsigned)__mul24(gy, W) + (unsigned)gx) * 4u;
                                 p[k] = ld_off<float>(prev, i);
@@ -744,6 +847,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                             }
                         }
                     }
+                    OFLK_STAMP(1);   // [1] carry -> LDS, addresses, issue of the coalesced loads (prev, u, v)
                     {
                         int r = r0, c = c0;
     #pragma unroll
@@ -754,7 +858,8 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     #pragma unroll
                                 for (int j = 0; j < BATCH; j++) {
                                     if (k0 + j < NE && (k0 + j) * 256 < ncells) {
-                                        int gy = clamp0(y0 - R + min(r, AH - 1), Hm1);
+                                        const int rr = ((OFLK_G & 4) && (k0 + j + 1) * 256 <= ncells) ? r : min(r, AH - 1);
+                                        int gy = clamp0(y0 - R + rr, Hm1);
                                         int gx = clamp0(x0 - R + c, Wm1);
                                         tp[j] = lean_taps(lg, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
                                         // two 8-byte gathers per cell (the x pair of each tap row)
@@ -763,6 +868,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                                         if (c >= AW) { c -= AW; r += 1; }
                                     }
                                 }
+                                OFLK_STAMP(k0 == 0 ? 2 : 4);   // [2]/[4] wait for u, v; taps; gathers issued
     #pragma unroll
                                 for (int j = 0; j < BATCH; j++)
                                     if (k0 + j < NE && (k0 + j) * 256 < ncells) {
@@ -770,6 +876,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                                         pin(q[k0 + j]);  // finished here, not sunk to its use after the last batch
                                     }
                                 __builtin_amdgcn_sched_barrier(0);  // one batch of taps in flight at a time
+                                OFLK_STAMP(k0 == 0 ? 3 : 5);   // [3]/[5] wait for the gathers; fp64 tap sums
                             }
                         }
                     }
@@ -778,7 +885,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     #pragma unroll
                         for (int k = 0; k < NE; k++) {
                             if (k * 256 < ncells) {
-                                if (r < AH) {
+                                if (((OFLK_G & 2) && (k + 1) * 256 <= ncells) || r < AH) {   // cell k exists for every thread unless it is the last
                                     float sum = p[k] + q[k];
                                     s_avg[r * AS + c + SC] = sum * 0.5f;
                                     s_it[r * AS + c + SC] = p[k] - q[k];
@@ -840,7 +947,9 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
             };
             if (rstart == 0) stage1(std::integral_constant<int, 0>{});
             else stage1(std::integral_constant<int, 2 * R>{});
+            OFLK_STAMP(6);    // [6] avg / It -> LDS
             __syncthreads();
+            OFLK_STAMP(7);    // [7] barrier 1
             // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
 #pragma unroll
             for (int k = 0; k < NG; k++) {
@@ -853,17 +962,22 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                 float a_0m = ap[-1], a_0p = ap[1];
                 float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
                 float ix = a_pp * -0.125f;
+                float iy = a_pp * -0.125f;
+                if constexpr ((OFLK_ABLATE & 16) != 0) {
+                    ix = a_0p + a_0m;
+                    iy = a_p0 + a_m0;
+                } else {
                 ix = fmaf(a_pm, 0.125f, ix);
                 ix = fmaf(a_0p, -0.25f, ix);
                 ix = fmaf(a_0m, 0.25f, ix);
                 ix = fmaf(a_mp, -0.125f, ix);
                 ix = fmaf(a_mm, 0.125f, ix);
-                float iy = a_pp * -0.125f;
                 iy = fmaf(a_p0, -0.25f, iy);
                 iy = fmaf(a_pm, -0.125f, iy);
                 iy = fmaf(a_mp, 0.125f, iy);
                 iy = fmaf(a_m0, 0.25f, iy);
                 iy = fmaf(a_mm, 0.125f, iy);
+                }
                 gix[k] = ix;
                 giy[k] = iy;
                 git[k] = s_it[(r + 1) * AS + (c + GC)];
@@ -873,43 +987,70 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
                     int qi = tid + j * 256;
-                    if (qi < NCARRY) {
+                    if (((OFLK_G & 1) && (j + 1) * 256 <= NCARRY) || qi < NCARRY) {
                         carry_a[j] = s_avg[k5TY * AS + qi];
                         carry_i[j] = s_it[k5TY * AS + qi];
                     }
                 }
             }
+            OFLK_STAMP(8);    // [8] stage 2: Sobel from LDS, carry rows
             __syncthreads();  // everyone is done reading avg / It: the planes may overwrite them
+            OFLK_STAMP(9);    // [9] barrier 2
         }
         // ---- products into the interleaved planes --------------------------------
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             int e = tid + k * 256;
-            if (e < PH * PW) {
+            if (((OFLK_G & 8) && (k + 1) * 256 <= PH * PW) || e < PH * PW) {   // only the last k is partial
                 float ix = gix[k], iy = giy[k], itv = git[k];
                 s_pa[e] = make_float2(ix * ix, iy * iy);
                 s_pb[e] = make_float2(ix * iy, ix * itv);
                 s_pc[e] = iy * itv;
             }
         }
+        OFLK_STAMP(10);   // [10] products -> LDS
         __syncthreads();
+        OFLK_STAMP(11);   // [11] barrier 3
 
+#if OFLK_L2_PREFETCH
+        // Pull the next chained tile's new staging rows (prev, flow u / v, and the same rows of curr)
+        // towards this XCD's L2 while stage 3 computes: one 4-byte load per 64-byte line, results
+        // consumed (by nothing) at the end of the tile.  Speed only.
+        float pf[3] = {0.0f, 0.0f, 0.0f};
+        if (CHAIN && MODE == MODE_ITER && it + 1 < ntile) {
+            const int plane_id = tid & 3, slot = tid >> 2;                // 64 threads per plane
+            const float *__restrict__ pl = plane_id == 0 ? prev : plane_id == 1 ? curr
+                                           : (plane_id == 2 ? a.fu[sel] : a.fv[sel]) + (size_t)b * plane;
+            constexpr int LPR = 6;                                        // 64-byte lines a 70-cell row may touch
+            const unsigned col0 = (unsigned)max(x0 - R, 0) * 4u & ~63u;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int idx = slot + 64 * k;
+                if (idx < k5TY * LPR) {
+                    const int rr = idx / LPR, ll = idx - rr * LPR;
+                    const int gy = min(y0 + k5TY + R + rr, H - 1);
+                    const unsigned colb = min(col0 + 64u * ll, (unsigned)(W - 1) * 4u);
+                    pf[k] = ld_off<float>(pl, (unsigned)__mul24(gy, W) * 4u + colb);
+                }
+            }
+        }
+#endif
         // ---- stage 3: window sums in NumPy order (pk over plane pairs), solve, write -----
         // thread = 2 (x) by NY (y) outputs; a half-wave spans one tile row, so the
         // 16-byte LDS reads of 32 adjacent lanes are contiguous (conflict-free)
         constexpr int NY = k5NY;
         constexpr int RW = 2 + 2 * HW;   // product columns a thread reads per row
         const int tx = tid & 31, ty = tid >> 5;
-        float2 sA[NY][2], sB[NY][2];
+        Sum2 sA[NY][2], sB[NY][2];
         float sC[NY][2];
         // rows of the interleaved planes: RW float2 = RW/2 aligned 16-byte reads; RW floats = RW/2 8-byte reads
-        auto load_f2 = [](const float2 *src, float2 (&row)[RW]) {
+        auto load_f2 = [](const float2 *src, Sum2 (&row)[RW]) {
             const float4 *r4 = reinterpret_cast<const float4 *>(src);
 #pragma unroll
             for (int j = 0; j < RW / 2; j++) {
                 float4 qv = r4[j];
-                row[2 * j] = make_float2(qv.x, qv.y);
-                row[2 * j + 1] = make_float2(qv.z, qv.w);
+                row[2 * j] = sum2(qv.x, qv.y);
+                row[2 * j + 1] = sum2(qv.z, qv.w);
             }
         };
         auto load_f1 = [](const float *src, float (&row)[RW]) {
@@ -923,19 +1064,19 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         };
         if constexpr (HW == 2) {
             const float2 *ba = &s_pa[(NY * ty) * PW + 2 * tx];
-            patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(ba + i * PW, row); }, sA);
+            patch5_sums<Sum2, NY>([&](int i, Sum2 (&row)[6]) { load_f2(ba + i * PW, row); }, sA);
             const float2 *bb = &s_pb[(NY * ty) * PW + 2 * tx];
-            patch5_sums<float2, NY>([&](int i, float2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
+            patch5_sums<Sum2, NY>([&](int i, Sum2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
             const float *bc = &s_pc[(NY * ty) * PW + 2 * tx];
             patch5_sums<float, NY>([&](int i, float (&row)[6]) { load_f1(bc + i * PW, row); }, sC);
         } else {
 #pragma unroll
             for (int oy = 0; oy < NY; oy++) {
                 const float2 *ba = &s_pa[(NY * ty + oy) * PW + 2 * tx];
-                window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(ba + i * PW, row); }, sA[oy]);
+                window_sums_row<Sum2, HW, 2>([&](int i, Sum2 (&row)[RW]) { load_f2(ba + i * PW, row); }, sA[oy]);
                 __builtin_amdgcn_sched_barrier(0);
                 const float2 *bb = &s_pb[(NY * ty + oy) * PW + 2 * tx];
-                window_sums_row<float2, HW, 2>([&](int i, float2 (&row)[RW]) { load_f2(bb + i * PW, row); }, sB[oy]);
+                window_sums_row<Sum2, HW, 2>([&](int i, Sum2 (&row)[RW]) { load_f2(bb + i * PW, row); }, sB[oy]);
                 __builtin_amdgcn_sched_barrier(0);
                 const float *bc = &s_pc[(NY * ty + oy) * PW + 2 * tx];
                 window_sums_row<float, HW, 2>([&](int i, float (&row)[RW]) { load_f1(bc + i * PW, row); }, sC[oy]);
@@ -943,6 +1084,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
             }
         }
 
+        OFLK_STAMP(12);   // [12] stage 3: window sums
         const int gxb = x0 + 2 * tx;
         float su = 0.0f, sv = 0.0f;
         float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
@@ -1029,14 +1171,27 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                 s_red[1][tid >> 6] = (double)sv;
             }
         }
+#if OFLK_L2_PREFETCH
+        asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]));
+#endif
+        OFLK_STAMP(13);   // [13] solve, flow += d, stores, |d| reduction
         // stage 3 has read the planes (the next tile's staging overwrites them) and s_red is complete
         if (MODE == MODE_ITER || (CHAIN && it + 1 < ntile)) __syncthreads();
+        OFLK_STAMP(14);   // [14] barrier 4
         if (MODE == MODE_ITER && tid == 0) {
             blk_u += (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
             blk_v += (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
         }
     }
     if (MODE == MODE_ITER && threadIdx.x == 0) lk_report(a, b, blk_u, blk_v);
+#ifdef OFLK_STAMPS
+    __syncthreads();
+    if (a.stamps) {
+        if (threadIdx.x < 4) s_st[threadIdx.x][0][15] = (unsigned)ntile;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * 8 * 16; i += 256) a.stamps[(size_t)blockIdx.x * 512 + i] = (&s_st[0][0][0])[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1246,23 +1401,51 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
     if (j0 + kPTW >= a.Wo) xlo = min(xlo, max(W - 2, 0));
 
     // ---- A: input tile, reflect-extended; all of a thread's loads go out before the
-    // first LDS write (one memory latency per tile instead of one per element) ---------
+    // first LDS write (one memory latency per tile instead of one per element).
+    // Element k of a thread is e = tid + 256 k; its (row, col) advance by (QA, RA) with a
+    // carry at kPIW columns, so the only division is the one that places element 0.
+    // Three block-uniform cases: the tile's source span lies inside the image (plain
+    // addresses: every tile but the frame's border ring), it leaves the image by less than
+    // one image size (one mirror step, no division), anything else (tiny images). ------
     {
         constexpr int NA = (kPIH * kPIW + 255) / 256;  // 17 elements per thread
+        constexpr int QA = 256 / kPIW, RA = 256 % kPIW;
+        constexpr int NLAST = kPIH * kPIW - (NA - 1) * 256;   // threads that own an element NA-1
+        const int ybase = ylo - 8, xbase = xlo - 8;
+        const int r0 = tid / kPIW, c0 = tid - r0 * kPIW;
         float vals[NA];
+        if (ybase >= 0 && ybase + kPIH <= H && xbase >= 0 && xbase + kPIW <= W) {
+            unsigned off = ((unsigned)__mul24(ybase + r0, W) + (unsigned)(xbase + c0)) * 4u;
+            const unsigned step = ((unsigned)__mul24(QA, W) + RA) * 4u, wrap = (unsigned)(W - kPIW) * 4u;
+            int c = c0;
 #pragma unroll
-        for (int k = 0; k < NA; k++) {
-            int e = min(tid + k * 256, kPIH * kPIW - 1);
-            int r = e / kPIW, c = e - r * kPIW;
-            int gy = reflect_idx(ylo - 8 + r, H);
-            int gx = reflect_idx(xlo - 8 + c, W);
-            vals[k] = src[(unsigned)(gy * W + gx)];
+            for (int k = 0; k < NA; k++) {
+                if (k < NA - 1 || tid < NLAST) vals[k] = ld_off<float>(src, off);
+                off += step; c += RA;
+                if (c >= kPIW) { c -= kPIW; off += wrap; }
+            }
+        } else {
+            // one mirror step covers indices in [-n, 2n): scipy "reflect" (d c b a | a b c d | d c b a)
+            const bool one_step = ybase >= -H && ybase + kPIH <= 2 * H && xbase >= -W && xbase + kPIW <= 2 * W;
+            int r = r0, c = c0;
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                int gy = ybase + r, gx = xbase + c;
+                if (one_step) {
+                    gy = gy < 0 ? -1 - gy : (gy >= H ? 2 * H - 1 - gy : gy);
+                    gx = gx < 0 ? -1 - gx : (gx >= W ? 2 * W - 1 - gx : gx);
+                } else {
+                    gy = reflect_idx(gy, H);
+                    gx = reflect_idx(gx, W);
+                }
+                if (k < NA - 1 || tid < NLAST) vals[k] = ld_off<float>(src, ((unsigned)__mul24(gy, W) + (unsigned)gx) * 4u);
+                c += RA; r += QA;
+                if (c >= kPIW) { c -= kPIW; r += 1; }
+            }
         }
 #pragma unroll
-        for (int k = 0; k < NA; k++) {
-            int e = tid + k * 256;
-            if (e < kPIH * kPIW) s_in[e] = vals[k];
-        }
+        for (int k = 0; k < NA; k++)
+            if (k < NA - 1 || tid < NLAST) s_in[tid + k * 256] = vals[k];
     }
     __syncthreads();
 

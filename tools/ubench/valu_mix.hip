@@ -29,6 +29,20 @@ __global__ void k(float *out, int iters)
         if (KIND == 14) { REP8(asm volatile("v_div_fixup_f32 %0, %0, %4, %5\n v_div_fixup_f32 %1, %1, %4, %5\n v_div_fixup_f32 %2, %2, %4, %5\n v_div_fixup_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f));) }
         if (KIND == 15) { REP8(asm volatile("v_div_scale_f32 %0, vcc, %0, %4, %5\n v_div_scale_f32 %1, vcc, %1, %4, %5\n v_div_scale_f32 %2, vcc, %2, %4, %5\n v_div_scale_f32 %3, vcc, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) : "vcc");) }
         if (KIND == 16) { REP8(asm volatile("v_div_fmas_f32 %0, %0, %4, %5\n v_div_fmas_f32 %1, %1, %4, %5\n v_div_fmas_f32 %2, %2, %4, %5\n v_div_fmas_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f) : "vcc");) }
+        if (KIND == 17) { REP8(asm volatile("v_min_f64 %0, %0, %4\n v_min_f64 %1, %1, %4\n v_min_f64 %2, %2, %4\n v_min_f64 %3, %3, %4" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd) : "v"(da));) }
+        if (KIND == 18) { REP8(asm volatile("v_cmp_le_u64 vcc, %0, %4\n v_cmp_le_u64 vcc, %1, %4\n v_cmp_le_u64 vcc, %2, %4\n v_cmp_le_u64 vcc, %3, %4" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd) : "v"(da) : "vcc");) }
+        if (KIND == 19) { REP8(asm volatile("v_mov_b32_dpp %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));) }
+        if (KIND == 20) { REP8(asm volatile("v_add_f32_dpp %0, %4, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %4, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %4, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %4, %3 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));) }
+        if (KIND == 21) { REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd) : "v"(da));) }
+        if (KIND == 22) { REP8(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd) : "v"(da));) }
+        if (KIND == 23) { REP8(asm volatile("v_pk_add_f16 %0, %0, %4\n v_pk_add_f16 %1, %1, %4\n v_pk_add_f16 %2, %2, %4\n v_pk_add_f16 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));) }
+        if (KIND == 24) { REP8(asm volatile("v_pk_fma_f16 %0, %0, %4, %4\n v_pk_fma_f16 %1, %1, %4, %4\n v_pk_fma_f16 %2, %2, %4, %4\n v_pk_fma_f16 %3, %3, %4, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));) }
+        if (KIND == 25) { REP8(asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd) : "v"(a), "v"(b), "v"(c), "v"(d));) }
+        if (KIND == 26) { REP8(asm volatile("v_floor_f64 %0, %0\n v_floor_f64 %1, %1\n v_floor_f64 %2, %2\n v_floor_f64 %3, %3" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd));) }
+        if (KIND == 27) { REP8(asm volatile("v_cvt_i32_f64 %0, %4\n v_cvt_i32_f64 %1, %5\n v_cvt_i32_f64 %2, %6\n v_cvt_i32_f64 %3, %7" : "+v"(ia), "+v"(ib), "+v"(ic), "+v"(id) : "v"(da), "v"(db), "v"(dc), "v"(dd));) }
+        if (KIND == 28) { REP8(asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(da), "v"(db), "v"(dc), "v"(dd));) }
+        if (KIND == 29) { REP8(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd) : "v"(da));) }
+        if (KIND == 30) { REP8(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_add_f32 %1, %1, %4\n v_cndmask_b32 %2, %2, %4, vcc\n v_add_f32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "vcc");) }
     }
     float s = a + b + c + d + e + f + g + h + ia + ib + ic + id + (float)(da + db + dc + dd);
     if (s == 12345.678f) out[1] = s;
@@ -74,5 +88,19 @@ int main()
     run<14>("v_div_fixup_f32", d_out);
     run<15>("v_div_scale_f32", d_out);
     run<16>("v_div_fmas_f32", d_out);
+    run<17>("v_min_f64", d_out);
+    run<18>("v_cmp_le_u64 vcc", d_out);
+    run<19>("v_mov_b32_dpp row_shr", d_out);
+    run<20>("v_add_f32_dpp wave_shr", d_out);
+    run<21>("v_mul_f64", d_out);
+    run<22>("v_pk_mul_f32", d_out);
+    run<23>("v_pk_add_f16", d_out);
+    run<24>("v_pk_fma_f16", d_out);
+    run<25>("v_cvt_f64_f32", d_out);
+    run<26>("v_floor_f64", d_out);
+    run<27>("v_cvt_i32_f64", d_out);
+    run<28>("v_cvt_f32_f64", d_out);
+    run<29>("v_add_f64", d_out);
+    run<30>("cndmask/add mix", d_out);
     return 0;
 }
