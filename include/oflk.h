@@ -47,7 +47,8 @@ const char *oflk_version(void);
 int oflk_device_count(void);
 /* message of the last error raised on the calling thread ("" if none) */
 const char *oflk_last_error(void);
-/* device used by the host entry points (default 0) */
+/* device used by the host entry points (default 0).  Each device has its own plan cache and
+ * staging buffers; calls on different devices (from different host threads) run concurrently. */
 int oflk_set_device(int device);
 
 /* ---- host-pointer entry points: one per reference function ---------------- */
@@ -104,11 +105,18 @@ int oflk_pyramidal_batch(const float *prev, const float *curr, int B, int H, int
                          int window_size, int iters, float *u, float *v, float *residual_log,
                          int *iters_run);
 
+/* The two reads above for the host entry points: they address the plan the last oflk_pyramidal* call
+ * of this shape left in the current device's cache (OFLK_ERR_INVALID if there is none). */
+int oflk_pyramidal_last_level_flow(int B, int H, int W, int levels, int window_size, int iters, int level,
+                                   int pair, float *u, float *v);
+int oflk_pyramidal_last_uncertain(int B, int H, int W, int levels, int window_size, int iters, int *uncertain);
+
 /* ---- uint8 frames (the reference's on-disk format) ------------------------- */
 /* Same as the batch entry points, for raw 8-bit frames [B][H][W] as generate_test_suite.py
- * writes them (frame_0x.bin, :259-261).  The uint8 -> float32 conversion the verifier does
- * on the host (python/optical_flow_verifier.py:61-65) runs on the device; results are
- * identical to converting first. */
+ * writes them (frame_0x.bin, :259-261).  The kernels read the bytes themselves (2 B/px of frame
+ * traffic instead of 8; no float32 copy of the frames exists on the device): the uint8 -> float32
+ * conversion the verifier does on the host (python/optical_flow_verifier.py:61-65) happens in
+ * registers and is exact, so results are identical to converting first. */
 int oflk_single_scale_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
                          int window_size, float *u, float *v);
 int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
@@ -117,12 +125,41 @@ int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *curr, int 
 /* device-side conversion for pipelines that hold uint8 frames in HBM: d_out[i] = (float)d_in[i] */
 int oflk_u8_to_f32(const unsigned char *d_in, float *d_out, size_t n, void *stream);
 
+/* ---- one process, several GPUs ------------------------------------------------- */
+/* Frame pairs are independent units (python/lucas_kanade_pyramidal.py:141-228 touches only its two
+ * inputs), so a batch shards over GPUs with no data-path exchange: the B pairs are cut into n_gpus
+ * contiguous shards (oflk_shard_range), shard g runs on device g in a host thread of its own with
+ * its own plan, and every shard writes its slice of the host output arrays.  n_gpus <= 0 means all
+ * visible devices; n_gpus > visible devices is OFLK_ERR_INVALID; with n_gpus == 1 the call is
+ * oflk_*_batch on the device of oflk_set_device.  Results do not depend on n_gpus.
+ * (The multi-process form -- one rank per GPU, torch.distributed over RCCL -- is bench.py's.) */
+int oflk_single_scale_batch_multi(const float *prev, const float *curr, int B, int H, int W,
+                                  int window_size, int n_gpus, float *u, float *v);
+int oflk_pyramidal_batch_multi(const float *prev, const float *curr, int B, int H, int W, int levels,
+                               int window_size, int iters, int n_gpus, float *u, float *v,
+                               float *residual_log, int *iters_run);
+int oflk_pyramidal_u8_multi(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
+                            int levels, int window_size, int iters, int n_gpus, float *u, float *v,
+                            float *residual_log, int *iters_run);
+/* [begin, end) of `total` units owned by shard `shard` of `n_shards` (contiguous, sizes differ by at
+ * most one): the partition used above and by bench.py's ranks */
+void oflk_shard_range(int total, int shard, int n_shards, int *begin, int *end);
+
 /* ---- device-resident plan API (pipelines, bench) -------------------------- */
 typedef struct oflk_plan oflk_plan;
 
 /* Allocate the workspace (pyramids, flow ping-pong buffers, reduction scratch)
  * for B pairs of H x W on `device`.  levels = 1 and iters = 0 gives a plan that
- * can only run oflk_plan_single_scale. */
+ * can only run oflk_plan_single_scale.
+ *   window_size : 2 ... 11.  Kernels exist for the 3x3 ... 11x11 windows; like the reference
+ *                 (lucas_kanade_core.py:104, :110) a size w uses the (2*(w/2)+1)^2 window, so 4 and 5
+ *                 both mean 5x5.  Sizes 1 and > 11, which the reference accepts, return
+ *                 OFLK_ERR_UNSUPPORTED.
+ *   A plan is single-stream: it owns one per-call state block, so at most ONE pass of a plan may be
+ *   in flight at a time (enqueue passes of one plan on one stream, or synchronise between streams).
+ *   Device pointers: when W % 4 == 0 the kernels move 16 bytes per lane and want every plane
+ *   (d_prev, d_curr, d_u, d_v; uint8 frames: 4-byte) 16-byte aligned -- what hipMalloc and
+ *   torch allocations give.  Other alignments are accepted and take the element-wise kernels. */
 int oflk_plan_create(oflk_plan **plan, int device, int B, int H, int W, int levels,
                      int window_size, int iters);
 int oflk_plan_destroy(oflk_plan *plan);
@@ -134,10 +171,27 @@ int oflk_plan_single_scale(oflk_plan *plan, const float *d_prev, const float *d_
                            float *d_u, float *d_v, void *stream);
 int oflk_plan_pyramidal(oflk_plan *plan, const float *d_prev, const float *d_curr, float *d_u,
                         float *d_v, void *stream);
+/* the same passes on device-resident uint8 frames [B][H][W] (see "uint8 frames" above) */
+int oflk_plan_single_scale_u8(oflk_plan *plan, const unsigned char *d_prev, const unsigned char *d_curr,
+                              float *d_u, float *d_v, void *stream);
+int oflk_plan_pyramidal_u8(oflk_plan *plan, const unsigned char *d_prev, const unsigned char *d_curr,
+                           float *d_u, float *d_v, void *stream);
 
 /* After oflk_plan_pyramidal: copy the residual log / iteration counts of the last
  * enqueued pass to the host (synchronises `stream`).  Either pointer may be NULL. */
 int oflk_plan_read_log(oflk_plan *plan, float *residual_log, int *iters_run, void *stream);
+
+/* After oflk_plan_pyramidal + read_log: uncertain[b*levels + l] has bit k set when the early-exit test
+ * after iteration k of level l (python/lucas_kanade_pyramidal.py:221-223) was decided with a mean
+ * within 5e-5 (relative) of the 0.01 threshold.  The reference sums np.mean in fp32 (pairwise, in
+ * 8192-element pieces), the device in exact fixed point; the two can only decide differently inside
+ * that band, so 0 everywhere means "provably the reference's iteration counts".  Synchronises. */
+int oflk_plan_read_uncertain(oflk_plan *plan, int *uncertain, void *stream);
+
+/* Final flow of a coarser pyramid level (level < levels-1; the finest level's flow is the result) of
+ * pair `pair` of the last pass, to host arrays of that level's size -- what the reference hands to
+ * visualize_pyramid_level at python/lucas_kanade_pyramidal.py:226.  Synchronises. */
+int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, float *v, void *stream);
 
 /* Per-kernel timing with HIP events on the launch stream.  While enabled, every
  * kernel launch of the plan is bracketed by an event pair; oflk_plan_kernel_times

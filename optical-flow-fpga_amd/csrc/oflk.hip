@@ -14,8 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/oflk.h"
@@ -47,7 +49,7 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                              \
     } while (0)
 
-int g_device = 0;
+std::atomic<int> g_device{0};   // device of the host-pointer entry points (oflk_set_device)
 
 int ensure_device(int dev)
 {
@@ -173,8 +175,11 @@ struct oflk_plan {
     // slot only (its other slot is the caller's output buffers)
     float *flow[OFLK_MAX_LEVELS] = {nullptr};
     // per-call state, one allocation, zeroed by k_call_init at the start of every call:
-    //   acc[B][L][K][kAccShards][kAccStride] (u64) | iters_run[B][L] (i32) | log[B][L][K][2] (f32)
+    //   acc[B][L][K][kAccShards][kAccStride] (u64) | iters_run[B][L] (i32) | uncertain[B][L] (i32) | log[B][L][K][2] (f32)
     unsigned long long *state = nullptr;
+    // uint8 plans only, and only when the fused pyramid kernel cannot take the frames (it always can for
+    // scale 0.5 unless a level is tiny): float32 copies of the caller's frames, allocated on first need
+    float *u8_stage[2] = {nullptr, nullptr};
     GaussW gauss;
 #ifdef OFLK_STAMPS
     unsigned *stamps = nullptr;      // diagnostic build: per-wave section cycle sums of the last finest-level launch
@@ -196,10 +201,11 @@ struct oflk_plan {
     size_t n_acc() const { return (size_t)B * L * Kc() * kAccShards * kAccStride; }
     unsigned long long *acc() const { return state; }
     int *iters_run() const { return reinterpret_cast<int *>(state + n_acc()); }
-    float *log() const { return reinterpret_cast<float *>(iters_run() + (size_t)B * L); }
+    int *uncertain() const { return iters_run() + (size_t)B * L; }
+    float *log() const { return reinterpret_cast<float *>(uncertain() + (size_t)B * L); }
     size_t n_log() const { return (size_t)B * L * Kc() * 2; }
     // 32-bit words of the whole state block (rounded up to a multiple of 4)
-    size_t state_words() const { return ((2 * n_acc() + (size_t)B * L + n_log()) + 3) & ~(size_t)3; }
+    size_t state_words() const { return ((2 * n_acc() + 2 * (size_t)B * L + n_log()) + 3) & ~(size_t)3; }
 };
 
 namespace {
@@ -214,19 +220,32 @@ struct Prof {
         if (!p || !p->prof) return;
         if (p->prof_only >= 0 && cls != p->prof_only) return;
         if (p->pool.empty()) {
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
+            if (hipEventCreate(&a) != hipSuccess) { a = nullptr; return; }   // this launch goes untimed
+            if (hipEventCreate(&b) != hipSuccess) {
+                (void)hipEventDestroy(a);
+                a = b = nullptr;
+                return;
+            }
         } else {
             a = p->pool.back().first;
             b = p->pool.back().second;
             p->pool.pop_back();
         }
-        (void)hipEventRecord(a, s);
+        if (hipEventRecord(a, s) != hipSuccess) drop();
+    }
+    void drop()
+    {
+        (void)hipGetLastError();
+        p->pool.push_back({a, b});
+        a = b = nullptr;
     }
     ~Prof()
     {
         if (!a) return;
-        (void)hipEventRecord(b, s);
+        if (hipEventRecord(b, s) != hipSuccess) {
+            drop();
+            return;
+        }
         p->pending.push_back({a, b, cls});
     }
 };
@@ -244,8 +263,9 @@ unsigned long long conv_threshold(double count)
     return hi;
 }
 
+// u8: a.prev / a.curr point at uint8 frames (finest level of a uint8 plan); never with MODE_GRADS
 template <int MODE>
-int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_in, int B)
+int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_in, int B, bool u8 = false)
 {
     LkArgs a = a_in;
     a.B = B;
@@ -267,7 +287,8 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     const long per_slot = (long)B * tiles_x * tiles_y / resident;
     int cap = MODE == MODE_GRADS ? 1 : (int)std::min<long>(std::max(1, cap_env), per_slot / 5);
     cap = std::max(cap, (tiles_y + kMaxSegs / 2 - 1) / (kMaxSegs / 2));  // keep the table short
-    if (MODE == MODE_GRADS || hw > 2 || cap_env <= 1 || per_slot < 10) cap = 1;   // kLkChain
+    // seg_row holds tile rows as unsigned short
+    if (MODE == MODE_GRADS || hw > 2 || cap_env <= 1 || per_slot < 10 || tiles_y > 65535) cap = 1;   // kLkChain
     unsigned nblocks;
     if (cap <= 1) {
         a.nseg = 0;
@@ -277,7 +298,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         while (row < tiles_y) {
             const int rest = tiles_y - row;
             int len = std::min(cap, std::max(1, rest / 2));   // halving tail: 8,8,8,8,6,3,2,1,1 for 45 rows
-            if (n == kMaxSegs - 1) len = rest;  // cannot happen for cap chosen above; stay in bounds
+            if (n == kMaxSegs - 1) len = rest;  // the halving tail of a very tall frame can get here: last segment takes the rest
             a.seg_row[n++] = (unsigned short)row;
             row += len;
         }
@@ -300,11 +321,24 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         a.stamps = plan->stamps;
     }
 #endif
-    const bool vec = (a.W & 3) == 0;
-#define OFLK_LAUNCH_LKW(HWV)                                                          \
-    do {                                                                              \
-        if (vec) hipLaunchKernelGGL((k_lkw<HWV, MODE, true>), grid, dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL((k_lkw<HWV, MODE, false>), grid, dim3(256), 0, s, a);     \
+    // the VEC instantiation moves 16 / 8 bytes per lane: every plane must start 16-byte aligned
+    // (each row then does, W % 4 == 0); anything else takes the element-wise instantiation
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    auto al4 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3u) == 0; };
+    const bool frames_ok = u8 ? (al4(a.prev) && al4(a.curr)) : (al16(a.prev) && al16(a.curr));   // uint8: 4 pixels per dword
+    const bool vec = (a.W & 3) == 0 && frames_ok && al16(a.aux) && al16(a.fu[0]) && al16(a.fu[1]) && al16(a.fv[0]) &&
+                     al16(a.fv[1]);
+#define OFLK_LAUNCH_LKW(HWV)                                                                          \
+    do {                                                                                              \
+        if constexpr (MODE != MODE_GRADS) {                                                           \
+            if (u8) {                                                                                 \
+                if (vec) hipLaunchKernelGGL((k_lkw<HWV, MODE, true, unsigned char>), grid, dim3(256), 0, s, a);  \
+                else hipLaunchKernelGGL((k_lkw<HWV, MODE, false, unsigned char>), grid, dim3(256), 0, s, a);     \
+                break;                                                                                \
+            }                                                                                         \
+        }                                                                                             \
+        if (vec) hipLaunchKernelGGL((k_lkw<HWV, MODE, true>), grid, dim3(256), 0, s, a);                  \
+        else hipLaunchKernelGGL((k_lkw<HWV, MODE, false>), grid, dim3(256), 0, s, a);                     \
     } while (0)
     switch (hw) {
         case 1: OFLK_LAUNCH_LKW(1); break;
@@ -384,6 +418,7 @@ struct PyrExtra {
     size_t n_zero_words = 0;
     float *zero_u = nullptr, *zero_v = nullptr;   // coarsest-level flow planes to clear
     size_t n_zero_flow = 0;
+    bool u8 = false;                  // the input images are uint8 (the caller's frames of a uint8 plan)
 };
 
 int launch_call_init(oflk_plan *plan, hipStream_t s, const PyrExtra &x)
@@ -423,7 +458,8 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
         for (int k = 0; k <= 8; k++) a.w[k] = gauss.w[k];
         dim3 grid((wo + kPTW - 1) / kPTW, (ho + kPTH - 1) / kPTH, nimg);
         Prof pr(plan, s, KC_PYR_FUSED);
-        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, a);
+        if (extra && extra->u8) hipLaunchKernelGGL(k_pyr_down<unsigned char>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_pyr_down<float>, grid, dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         return OFLK_OK;
     }
@@ -443,10 +479,11 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
     {
         Prof pr(plan, s, KC_BLUR);
         hipLaunchKernelGGL((k_blur<0>), grid2d(w, h, nimg), dim3(256), 0, s, in, tmpA, h, w, gauss);
+        HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL((k_blur<1>), grid2d(w, h, nimg), dim3(256), 0, s, (const float *)tmpA, tmpB, h,
                            w, gauss);
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     ResampleArgs r{};
     r.in[0] = tmpB;
     r.out[0] = out;
@@ -489,6 +526,8 @@ void plan_free(oflk_plan *p)
     if (p->tmpA) (void)hipFree(p->tmpA);
     if (p->tmpB) (void)hipFree(p->tmpB);
     if (p->state) (void)hipFree(p->state);
+    for (auto &q : p->u8_stage)
+        if (q) (void)hipFree(q);
 #ifdef OFLK_STAMPS
     if (p->stamps) (void)hipFree(p->stamps);
 #endif
@@ -592,26 +631,71 @@ OFLK_API int oflk_plan_destroy(oflk_plan *plan)
 
 OFLK_API size_t oflk_plan_workspace_bytes(const oflk_plan *plan) { return plan ? plan->ws_bytes : 0; }
 
-OFLK_API int oflk_plan_single_scale(oflk_plan *p, const float *d_prev, const float *d_curr,
-                                    float *d_u, float *d_v, void *stream)
+namespace {
+int plan_single_scale(oflk_plan *p, const void *d_prev, const void *d_curr, bool u8, float *d_u, float *d_v,
+                      hipStream_t s)
 {
     if (!p || !d_prev || !d_curr || !d_u || !d_v) return fail(OFLK_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(p->device));
     LkArgs a{};
-    a.prev = d_prev; a.curr = d_curr;
+    a.prev = static_cast<const float *>(d_prev);   // element type is the kernel's PIX (launch_lk, u8)
+    a.curr = static_cast<const float *>(d_curr);
     a.fu[0] = d_u; a.fv[0] = d_v;
     a.H = p->H; a.W = p->W;
-    return launch_lk<MODE_SINGLE>(p, (hipStream_t)stream, KC_LK_SINGLE, p->hw, a, p->B);
+    return launch_lk<MODE_SINGLE>(p, s, KC_LK_SINGLE, p->hw, a, p->B, u8);
+}
+int plan_pyramidal(oflk_plan *p, const void *d_prev, const void *d_curr, bool u8, float *d_u, float *d_v, hipStream_t s);
+}  // namespace
+
+OFLK_API int oflk_plan_single_scale(oflk_plan *p, const float *d_prev, const float *d_curr,
+                                    float *d_u, float *d_v, void *stream)
+{
+    return plan_single_scale(p, d_prev, d_curr, false, d_u, d_v, (hipStream_t)stream);
+}
+
+OFLK_API int oflk_plan_single_scale_u8(oflk_plan *p, const unsigned char *d_prev, const unsigned char *d_curr,
+                                       float *d_u, float *d_v, void *stream)
+{
+    return plan_single_scale(p, d_prev, d_curr, true, d_u, d_v, (hipStream_t)stream);
 }
 
 OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float *d_curr, float *d_u,
                                  float *d_v, void *stream)
 {
-    if (!p || !d_prev || !d_curr || !d_u || !d_v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    return plan_pyramidal(p, d_prev, d_curr, false, d_u, d_v, (hipStream_t)stream);
+}
+
+OFLK_API int oflk_plan_pyramidal_u8(oflk_plan *p, const unsigned char *d_prev, const unsigned char *d_curr,
+                                    float *d_u, float *d_v, void *stream)
+{
+    return plan_pyramidal(p, d_prev, d_curr, true, d_u, d_v, (hipStream_t)stream);
+}
+
+namespace {
+int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, bool u8, float *d_u, float *d_v,
+                   hipStream_t s)
+{
+    if (!p || !d_prev_in || !d_curr_in || !d_u || !d_v) return fail(OFLK_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(p->device));
-    hipStream_t s = (hipStream_t)stream;
     const int B = p->B, L = p->L, K = p->K;
     int rc;
+    if (u8 && L > 1 &&
+        !pyr_fused_fits(p->dims[2 * (L - 1)], p->dims[2 * (L - 1) + 1], p->dims[2 * (L - 2)], p->dims[2 * (L - 2) + 1], p->gauss)) {
+        // the unfused pyramid kernels read float32: convert once and run the float path
+        const size_t n = (size_t)B * p->H * p->W;
+        size_t tot = 0;
+        for (auto &q : p->u8_stage)
+            if (!q && (rc = dmalloc(&q, n, &tot))) return rc;
+        p->ws_bytes += tot;
+        dim3 grid((unsigned)((n + 4095) / 4096));
+        hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, s, static_cast<const unsigned char *>(d_prev_in), p->u8_stage[0], n);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, s, static_cast<const unsigned char *>(d_curr_in), p->u8_stage[1], n);
+        HIP_TRY(hipGetLastError());
+        return plan_pyramidal(p, p->u8_stage[0], p->u8_stage[1], false, d_u, d_v, s);
+    }
+    // typed float for the common case; with u8 the kernels of the finest level read them as uint8
+    const float *d_prev = static_cast<const float *>(d_prev_in), *d_curr = static_cast<const float *>(d_curr_in);
 
     // the caller's buffers are the ping-pong slot the final flow lands in when no
     // level exits early at the finest level: slot K % 2
@@ -649,6 +733,7 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
             // prev and curr in one launch, images 0..B-1 from d_prev, B..2B-1 from d_curr
             first.in2 = d_curr;
             first.nsplit = B;
+            first.u8 = u8;
             rc = launch_pyr_down(p, p->gauss, s, d_prev, p->pyr[l], p->tmpA, p->tmpB, 2 * B, h, w, ho, wo, &first);
             if (rc) return rc;
         } else {
@@ -695,7 +780,7 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
             a.conv_thr = conv_threshold((double)n);
             a.level = l; a.iter = k; a.L = L; a.K = p->Kc();
             a.H = h; a.W = w;
-            rc = launch_lk<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, p->hw, a, B);
+            rc = launch_lk<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, p->hw, a, B, u8 && l == L - 1);
             if (rc) return rc;
         }
     }
@@ -715,6 +800,12 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
         }
         e.log = p->log();
         e.iters_run = p->iters_run();
+        e.uncertain = p->uncertain();
+        for (int l = 0; l < L; l++) {
+            const double t = (double)e.thr[l];
+            e.guard_lo[l] = (unsigned long long)std::floor(t * (1.0 - kDecisionGuard));
+            e.guard_hi[l] = (unsigned long long)std::ceil(t * (1.0 + kDecisionGuard));
+        }
         e.plane = (size_t)p->H * p->W;
         // few blocks per pair: the copy is the rare case, the common one is "nothing to do"
         dim3 grid((unsigned)std::min<size_t>((e.plane + 255) / 256, 128), B);
@@ -724,6 +815,7 @@ OFLK_API int oflk_plan_pyramidal(oflk_plan *p, const float *d_prev, const float 
     }
     return OFLK_OK;
 }
+}  // namespace
 
 OFLK_API int oflk_plan_read_log(oflk_plan *p, float *residual_log, int *iters_run, void *stream)
 {
@@ -754,6 +846,35 @@ OFLK_API long oflk_debug_stamps(oflk_plan *p, unsigned *out, long max_blocks)
     return (long)p->stamps_blocks;
 }
 #endif
+
+OFLK_API int oflk_plan_read_uncertain(oflk_plan *p, int *uncertain, void *stream)
+{
+    if (!p || !uncertain) return fail(OFLK_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(uncertain, p->uncertain(), (size_t)p->B * p->L * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_plan_read_level_flow(oflk_plan *p, int level, int pair, float *u, float *v, void *stream)
+{
+    if (!p || !u || !v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    if (level < 0 || level >= p->L - 1)
+        return fail(OFLK_ERR_INVALID, "level must be in [0,%d): the finest level's flow is the call's result", p->L - 1);
+    if (pair < 0 || pair >= p->B) return fail(OFLK_ERR_INVALID, "pair %d out of range [0,%d)", pair, p->B);
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)stream;
+    int executed = 0;
+    HIP_TRY(hipMemcpyAsync(&executed, p->iters_run() + (size_t)pair * p->L + level, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int slot = executed & 1;   // the ping-pong slot the level's last executed iteration wrote
+    const size_t n = p->npix(level);
+    HIP_TRY(hipMemcpyAsync(u, p->fu(level, slot) + (size_t)pair * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(v, p->fv(level, slot) + (size_t)pair * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return OFLK_OK;
+}
 
 OFLK_API int oflk_plan_set_profiling(oflk_plan *p, int enabled)
 {
@@ -797,8 +918,6 @@ OFLK_API int oflk_plan_kernel_times(oflk_plan *p, const char **names, double *to
 // =============================================================================
 namespace {
 
-std::mutex g_mu;
-
 struct Arena {
     std::vector<void *> blocks;
     ~Arena() { release(); }
@@ -817,40 +936,94 @@ struct Arena {
     }
 };
 
-// one cached plan for repeated host calls of the same shape (the verifier runs
-// 13 patterns of one size)
-oflk_plan *g_plan = nullptr;
-float *g_io[4] = {nullptr, nullptr, nullptr, nullptr};  // device prev, curr, u, v
-size_t g_io_elems = 0;
+// Per-device state of the host entry points: a small cache of plans keyed by shape (the verifier
+// alternates single-scale and pyramidal calls of one size; a caller may mix a few sizes) and the
+// device buffers the frames and flows are staged in.  Everything in a context lives on ITS device,
+// so switching devices (oflk_set_device, the multi-GPU entry points) never mixes allocations.
+constexpr int kMaxDevices = 64;
+constexpr size_t kPlanCache = 6;
 
-int host_plan(int B, int H, int W, int L, int win, int K, oflk_plan **out)
+struct HostCtx {
+    std::mutex mu;   // one host call at a time per device; different devices run concurrently
+    std::vector<oflk_plan *> plans;                          // most recently used first
+    float *io[4] = {nullptr, nullptr, nullptr, nullptr};    // device prev, curr, u, v
+    size_t io_elems = 0;
+    unsigned char *u8[2] = {nullptr, nullptr};              // device uint8 frames
+    size_t u8_elems = 0;
+};
+HostCtx g_ctx[kMaxDevices];
+
+// lock the context of `dev` and make the device current for the calling thread
+int acquire(int dev, HostCtx **out, std::unique_lock<std::mutex> &lk)
 {
-    if (g_plan && g_plan->device == g_device && g_plan->B == B && g_plan->H == H && g_plan->W == W &&
-        g_plan->L == L && g_plan->win == win && g_plan->K == K) {
-        *out = g_plan;
-    } else {
-        if (g_plan) {
-            plan_free(g_plan);
-            g_plan = nullptr;
+    if (dev < 0 || dev >= kMaxDevices) return fail(OFLK_ERR_INVALID, "device %d out of range", dev);
+    lk = std::unique_lock<std::mutex>(g_ctx[dev].mu);
+    int rc = ensure_device(dev);
+    if (rc) return rc;
+    *out = &g_ctx[dev];
+    return OFLK_OK;
+}
+
+int host_plan(HostCtx &c, int dev, int B, int H, int W, int L, int win, int K, oflk_plan **out)
+{
+    for (size_t i = 0; i < c.plans.size(); i++) {
+        oflk_plan *q = c.plans[i];
+        if (q->B == B && q->H == H && q->W == W && q->L == L && q->win == win && q->K == K) {
+            c.plans.erase(c.plans.begin() + (long)i);
+            c.plans.insert(c.plans.begin(), q);
+            *out = q;
+            return OFLK_OK;
         }
-        int rc = oflk_plan_create(&g_plan, g_device, B, H, W, L, win, K);
+    }
+    oflk_plan *q = nullptr;
+    int rc = oflk_plan_create(&q, dev, B, H, W, L, win, K);
+    if (rc == OFLK_ERR_NOMEM && !c.plans.empty()) {
+        // make room: drop every cached plan and try once more
+        for (oflk_plan *old : c.plans) plan_free(old);
+        c.plans.clear();
+        rc = oflk_plan_create(&q, dev, B, H, W, L, win, K);
+    }
+    if (rc) return rc;
+    c.plans.insert(c.plans.begin(), q);
+    while (c.plans.size() > kPlanCache) {
+        plan_free(c.plans.back());
+        c.plans.pop_back();
+    }
+    *out = q;
+    return OFLK_OK;
+}
+
+int host_io(HostCtx &c, size_t need)
+{
+    if (need <= c.io_elems) return OFLK_OK;
+    for (auto &q : c.io) {
+        if (q) (void)hipFree(q);
+        q = nullptr;
+    }
+    c.io_elems = 0;
+    size_t tot = 0;
+    for (auto &q : c.io) {
+        int rc = dmalloc(&q, need, &tot);
         if (rc) return rc;
-        *out = g_plan;
     }
-    size_t need = (size_t)B * H * W;
-    if (need > g_io_elems) {
-        for (auto &q : g_io) {
-            if (q) (void)hipFree(q);
-            q = nullptr;
-        }
-        g_io_elems = 0;
-        size_t tot = 0;
-        for (auto &q : g_io) {
-            int rc = dmalloc(&q, need, &tot);
-            if (rc) return rc;
-        }
-        g_io_elems = need;
+    c.io_elems = need;
+    return OFLK_OK;
+}
+
+int host_u8(HostCtx &c, size_t need)
+{
+    if (need <= c.u8_elems) return OFLK_OK;
+    for (auto &q : c.u8) {
+        if (q) (void)hipFree(q);
+        q = nullptr;
     }
+    c.u8_elems = 0;
+    size_t tot = 0;
+    for (auto &q : c.u8) {
+        int rc = dmalloc(&q, need, &tot);
+        if (rc) return rc;
+    }
+    c.u8_elems = need;
     return OFLK_OK;
 }
 
@@ -863,28 +1036,109 @@ int check_hw(const void *a, const void *b, int H, int W)
     return OFLK_OK;
 }
 
-}  // namespace
+// One batch on one device, host pointers in and out.  PIXELS: float or unsigned char frames (the
+// uint8 kernels read the frames as they are: no float32 copy of them exists on the device).
+// levels == 0 selects single-scale.
+template <class PIXELS>
+int run_batch_on(int dev, const PIXELS *prev, const PIXELS *curr, int B, int H, int W, int levels, int window_size,
+                 int iters, float *u, float *v, float *residual_log, int *iters_run)
+{
+    constexpr bool U8 = sizeof(PIXELS) == 1;
+    int rc = check_hw(prev, curr, H, W);
+    if (rc) return rc;
+    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(dev, &c, lk))) return rc;
+    const bool single = levels == 0;
+    oflk_plan *p = nullptr;
+    if ((rc = host_plan(*c, dev, B, H, W, single ? 1 : levels, window_size, single ? 0 : iters, &p))) return rc;
+    const size_t n = (size_t)B * H * W, obytes = n * sizeof(float);
+    if ((rc = host_io(*c, n))) return rc;
+    const void *dp, *dc;
+    if (U8) {
+        if ((rc = host_u8(*c, n))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->u8[0], prev, n, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(c->u8[1], curr, n, hipMemcpyHostToDevice, nullptr));
+        dp = c->u8[0];
+        dc = c->u8[1];
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->io[0], prev, obytes, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(c->io[1], curr, obytes, hipMemcpyHostToDevice, nullptr));
+        dp = c->io[0];
+        dc = c->io[1];
+    }
+    rc = single ? plan_single_scale(p, dp, dc, U8, c->io[2], c->io[3], nullptr)
+                : plan_pyramidal(p, dp, dc, U8, c->io[2], c->io[3], nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(u, c->io[2], obytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, c->io[3], obytes, hipMemcpyDeviceToHost, nullptr));
+    if (single) {
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return OFLK_OK;
+    }
+    return oflk_plan_read_log(p, residual_log, iters_run, nullptr);
+}
 
-OFLK_API int oflk_single_scale_batch(const float *prev, const float *curr, int B, int H, int W,
-                                     int window_size, float *u, float *v)
+// contiguous share of `total` units for shard `i` of `n`; sizes differ by at most one
+// (the rule of optical-flow-fpga_amd/python/oflk_dist.py shard_range)
+void shard_range(int total, int i, int n, int *begin, int *end)
+{
+    const int base = total / n, extra = total % n;
+    *begin = i * base + std::min(i, extra);
+    *end = *begin + base + (i < extra ? 1 : 0);
+}
+
+// Frame pairs are independent units (lucas_kanade_pyramidal.py:141-228 touches only its two inputs):
+// the batch is cut into n_gpus contiguous shards, each run by its own host thread on its own device
+// with its own plan; no data crosses between devices.
+template <class PIXELS>
+int run_batch_multi(const PIXELS *prev, const PIXELS *curr, int B, int H, int W, int levels, int window_size, int iters,
+                    int n_gpus, float *u, float *v, float *residual_log, int *iters_run)
 {
     int rc = check_hw(prev, curr, H, W);
     if (rc) return rc;
     if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
     if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
-    std::lock_guard<std::mutex> lk(g_mu);
-    oflk_plan *p = nullptr;
-    rc = host_plan(B, H, W, 1, window_size, 0, &p);
-    if (rc) return rc;
-    size_t bytes = (size_t)B * H * W * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(g_io[0], prev, bytes, hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(g_io[1], curr, bytes, hipMemcpyHostToDevice, nullptr));
-    rc = oflk_plan_single_scale(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    const int ndev = oflk_device_count();
+    if (ndev < 1) return fail(OFLK_ERR_NO_DEVICE, "no usable HIP device; liboflk has no CPU path");
+    if (n_gpus <= 0) n_gpus = ndev;
+    if (n_gpus > ndev) return fail(OFLK_ERR_INVALID, "n_gpus = %d but %d device(s) visible", n_gpus, ndev);
+    n_gpus = std::min(n_gpus, B);   // never more shards than pairs
+    if (n_gpus == 1)
+        return run_batch_on<PIXELS>(g_device.load(), prev, curr, B, H, W, levels, window_size, iters, u, v, residual_log,
+                                    iters_run);
+    const size_t plane = (size_t)H * W;
+    const int Lc = std::max(levels, 1), Kc = std::max(iters, 1);
+    std::vector<int> codes((size_t)n_gpus, OFLK_OK);
+    std::vector<std::string> msgs((size_t)n_gpus);
+    std::vector<std::thread> workers;
+    for (int g = 0; g < n_gpus; g++) {
+        workers.emplace_back([&, g]() {
+            int b0, b1;
+            shard_range(B, g, n_gpus, &b0, &b1);
+            if (b1 <= b0) return;
+            const size_t off = (size_t)b0 * plane;
+            codes[(size_t)g] = run_batch_on<PIXELS>(g, prev + off, curr + off, b1 - b0, H, W, levels, window_size, iters,
+                                                    u + off, v + off,
+                                                    residual_log ? residual_log + (size_t)b0 * Lc * Kc * 2 : nullptr,
+                                                    iters_run ? iters_run + (size_t)b0 * Lc : nullptr);
+            if (codes[(size_t)g]) msgs[(size_t)g] = t_err;   // the worker's thread-local message
+        });
+    }
+    for (auto &w : workers) w.join();
+    for (int g = 0; g < n_gpus; g++)
+        if (codes[(size_t)g]) return fail(codes[(size_t)g], "device %d: %s", g, msgs[(size_t)g].c_str());
     return OFLK_OK;
+}
+
+}  // namespace
+
+OFLK_API int oflk_single_scale_batch(const float *prev, const float *curr, int B, int H, int W,
+                                     int window_size, float *u, float *v)
+{
+    return run_batch_on<float>(g_device.load(), prev, curr, B, H, W, 0, window_size, 0, u, v, nullptr, nullptr);
 }
 
 OFLK_API int oflk_single_scale(const float *prev, const float *curr, int H, int W, int window_size,
@@ -897,96 +1151,105 @@ OFLK_API int oflk_pyramidal_batch(const float *prev, const float *curr, int B, i
                                   int levels, int window_size, int iters, float *u, float *v,
                                   float *residual_log, int *iters_run)
 {
-    int rc = check_hw(prev, curr, H, W);
-    if (rc) return rc;
-    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
-    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
-    std::lock_guard<std::mutex> lk(g_mu);
-    oflk_plan *p = nullptr;
-    rc = host_plan(B, H, W, levels, window_size, iters, &p);
-    if (rc) return rc;
-    size_t bytes = (size_t)B * H * W * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(g_io[0], prev, bytes, hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(g_io[1], curr, bytes, hipMemcpyHostToDevice, nullptr));
-    rc = oflk_plan_pyramidal(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
-    return oflk_plan_read_log(p, residual_log, iters_run, nullptr);
+    if (levels < 1) return fail(OFLK_ERR_INVALID, "levels must be in [1,%d] (got %d)", OFLK_MAX_LEVELS, levels);
+    return run_batch_on<float>(g_device.load(), prev, curr, B, H, W, levels, window_size, iters, u, v, residual_log,
+                               iters_run);
+}
+
+OFLK_API int oflk_pyramidal(const float *prev, const float *curr, int H, int W, int levels,
+                            int window_size, int iters, float *u, float *v, float *residual_log,
+                            int *iters_run)
+{
+    return oflk_pyramidal_batch(prev, curr, 1, H, W, levels, window_size, iters, u, v, residual_log,
+                                iters_run);
 }
 
 // ---- uint8 ingestion: raw 8-bit frames as the reference stores them (frame_0x.bin,
-// generate_test_suite.py:259-261); the uint8 -> float32 conversion the verifier performs
-// on the host (optical_flow_verifier.py:61-65) runs on the device instead ----------------
-namespace {
-unsigned char *g_u8[2] = {nullptr, nullptr};
-size_t g_u8_elems = 0;
-
-int stage_u8(const unsigned char *prev, const unsigned char *curr, size_t n)
-{
-    if (n > g_u8_elems) {
-        for (auto &q : g_u8) {
-            if (q) (void)hipFree(q);
-            q = nullptr;
-        }
-        g_u8_elems = 0;
-        size_t tot = 0;
-        for (auto &q : g_u8) {
-            int rc = dmalloc(&q, n, &tot);
-            if (rc) return rc;
-        }
-        g_u8_elems = n;
-    }
-    HIP_TRY(hipMemcpyAsync(g_u8[0], prev, n, hipMemcpyHostToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(g_u8[1], curr, n, hipMemcpyHostToDevice, nullptr));
-    dim3 grid((unsigned)((n + 4095) / 4096));
-    hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, nullptr, (const unsigned char *)g_u8[0], g_io[0], n);
-    hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, nullptr, (const unsigned char *)g_u8[1], g_io[1], n);
-    HIP_TRY(hipGetLastError());
-    return OFLK_OK;
-}
-}  // namespace
-
+// generate_test_suite.py:259-261).  The kernels read the bytes directly (4 pixels per dword in the
+// single-scale staging, byte gathers in the warp): the uint8 -> float32 conversion the verifier
+// performs on the host (optical_flow_verifier.py:61-65) happens in registers ------------------
 OFLK_API int oflk_single_scale_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
                                   int window_size, float *u, float *v)
 {
-    int rc = check_hw(prev, curr, H, W);
-    if (rc) return rc;
-    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
-    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
-    std::lock_guard<std::mutex> lk(g_mu);
-    oflk_plan *p = nullptr;
-    rc = host_plan(B, H, W, 1, window_size, 0, &p);
-    if (rc) return rc;
-    size_t n = (size_t)B * H * W, bytes = n * sizeof(float);
-    if ((rc = stage_u8(prev, curr, n))) return rc;
-    rc = oflk_plan_single_scale(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    return OFLK_OK;
+    return run_batch_on<unsigned char>(g_device.load(), prev, curr, B, H, W, 0, window_size, 0, u, v, nullptr, nullptr);
 }
 
 OFLK_API int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
                                int levels, int window_size, int iters, float *u, float *v,
                                float *residual_log, int *iters_run)
 {
-    int rc = check_hw(prev, curr, H, W);
+    if (levels < 1) return fail(OFLK_ERR_INVALID, "levels must be in [1,%d] (got %d)", OFLK_MAX_LEVELS, levels);
+    return run_batch_on<unsigned char>(g_device.load(), prev, curr, B, H, W, levels, window_size, iters, u, v,
+                                       residual_log, iters_run);
+}
+
+// ---- one process, several GPUs: the batch sharded over devices 0 .. n_gpus-1 ---------------
+OFLK_API int oflk_single_scale_batch_multi(const float *prev, const float *curr, int B, int H, int W,
+                                           int window_size, int n_gpus, float *u, float *v)
+{
+    return run_batch_multi<float>(prev, curr, B, H, W, 0, window_size, 0, n_gpus, u, v, nullptr, nullptr);
+}
+
+OFLK_API int oflk_pyramidal_batch_multi(const float *prev, const float *curr, int B, int H, int W, int levels,
+                                        int window_size, int iters, int n_gpus, float *u, float *v,
+                                        float *residual_log, int *iters_run)
+{
+    if (levels < 1) return fail(OFLK_ERR_INVALID, "levels must be in [1,%d] (got %d)", OFLK_MAX_LEVELS, levels);
+    return run_batch_multi<float>(prev, curr, B, H, W, levels, window_size, iters, n_gpus, u, v, residual_log, iters_run);
+}
+
+OFLK_API int oflk_pyramidal_u8_multi(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
+                                     int levels, int window_size, int iters, int n_gpus, float *u, float *v,
+                                     float *residual_log, int *iters_run)
+{
+    if (levels < 1) return fail(OFLK_ERR_INVALID, "levels must be in [1,%d] (got %d)", OFLK_MAX_LEVELS, levels);
+    return run_batch_multi<unsigned char>(prev, curr, B, H, W, levels, window_size, iters, n_gpus, u, v, residual_log,
+                                          iters_run);
+}
+
+namespace {
+// the cached plan of an earlier host call of this shape on the current device (not created here)
+int cached_plan(HostCtx &c, int B, int H, int W, int L, int win, int K, oflk_plan **out)
+{
+    for (oflk_plan *q : c.plans)
+        if (q->B == B && q->H == H && q->W == W && q->L == L && q->win == win && q->K == K) {
+            *out = q;
+            return OFLK_OK;
+        }
+    return fail(OFLK_ERR_INVALID, "no pyramidal call of this shape (B=%d, %dx%d, %d levels, window %d, %d iterations) "
+                                  "has run on this device yet", B, W, H, L, win, K);
+}
+}  // namespace
+
+OFLK_API int oflk_pyramidal_last_level_flow(int B, int H, int W, int levels, int window_size, int iters, int level,
+                                            int pair, float *u, float *v)
+{
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    int rc = acquire(g_device.load(), &c, lk);
     if (rc) return rc;
-    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
-    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
-    std::lock_guard<std::mutex> lk(g_mu);
     oflk_plan *p = nullptr;
-    rc = host_plan(B, H, W, levels, window_size, iters, &p);
+    if ((rc = cached_plan(*c, B, H, W, levels, window_size, iters, &p))) return rc;
+    return oflk_plan_read_level_flow(p, level, pair, u, v, nullptr);
+}
+
+OFLK_API int oflk_pyramidal_last_uncertain(int B, int H, int W, int levels, int window_size, int iters, int *uncertain)
+{
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    int rc = acquire(g_device.load(), &c, lk);
     if (rc) return rc;
-    size_t n = (size_t)B * H * W, bytes = n * sizeof(float);
-    if ((rc = stage_u8(prev, curr, n))) return rc;
-    rc = oflk_plan_pyramidal(p, g_io[0], g_io[1], g_io[2], g_io[3], nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(u, g_io[2], bytes, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipMemcpyAsync(v, g_io[3], bytes, hipMemcpyDeviceToHost, nullptr));
-    return oflk_plan_read_log(p, residual_log, iters_run, nullptr);
+    oflk_plan *p = nullptr;
+    if ((rc = cached_plan(*c, B, H, W, levels, window_size, iters, &p))) return rc;
+    return oflk_plan_read_uncertain(p, uncertain, nullptr);
+}
+
+OFLK_API void oflk_shard_range(int total, int shard, int n_shards, int *begin, int *end)
+{
+    int b = 0, e = 0;
+    if (n_shards >= 1 && shard >= 0 && shard < n_shards && total >= 0) shard_range(total, shard, n_shards, &b, &e);
+    if (begin) *begin = b;
+    if (end) *end = e;
 }
 
 namespace {
@@ -1056,9 +1319,9 @@ OFLK_API int oflk_flow_metrics(const float *u, const float *v, int B, int H, int
     int rc = check_hw(u, v, H, W);
     if (rc) return rc;
     if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
-    std::lock_guard<std::mutex> lk(g_mu);
-    rc = ensure_device(g_device);
-    if (rc) return rc;
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
     Arena ar;
     const size_t n = (size_t)B * H * W;
     float *d_u = nullptr, *d_v = nullptr;
@@ -1078,23 +1341,15 @@ OFLK_API int oflk_u8_to_f32(const unsigned char *d_in, float *d_out, size_t n, v
     return OFLK_OK;
 }
 
-OFLK_API int oflk_pyramidal(const float *prev, const float *curr, int H, int W, int levels,
-                            int window_size, int iters, float *u, float *v, float *residual_log,
-                            int *iters_run)
-{
-    return oflk_pyramidal_batch(prev, curr, 1, H, W, levels, window_size, iters, u, v, residual_log,
-                                iters_run);
-}
-
 OFLK_API int oflk_compute_gradients(const float *prev, const float *curr, int H, int W, float *Ix,
                                     float *Iy, float *It)
 {
     int rc = check_hw(prev, curr, H, W);
     if (rc) return rc;
     if (!Ix || !Iy || !It) return fail(OFLK_ERR_INVALID, "NULL output");
-    std::lock_guard<std::mutex> lk(g_mu);
-    rc = ensure_device(g_device);
-    if (rc) return rc;
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
     Arena ar;
     size_t n = (size_t)H * W, bytes = n * sizeof(float);
     float *d[5];
@@ -1120,9 +1375,9 @@ OFLK_API int oflk_from_gradients(const float *Ix, const float *Iy, const float *
     if (!It || !u || !v) return fail(OFLK_ERR_INVALID, "NULL argument");
     int hw = 0;
     if ((rc = window_hw(window_size, &hw))) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
-    rc = ensure_device(g_device);
-    if (rc) return rc;
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
     Arena ar;
     size_t n = (size_t)H * W, bytes = n * sizeof(float);
     float *d[5];
@@ -1152,9 +1407,9 @@ OFLK_API int oflk_build_pyramid(const float *image, int H, int W, int levels, do
     if ((rc = level_dims(H, W, levels, scale_factor, dims))) return rc;
     for (int l = 0; l < levels; l++)
         if (!out_levels[l]) return fail(OFLK_ERR_INVALID, "out_levels[%d] is NULL", l);
-    std::lock_guard<std::mutex> lk(g_mu);
-    rc = ensure_device(g_device);
-    if (rc) return rc;
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
     GaussW gauss;
     if ((rc = make_gauss(1.0 / scale_factor, &gauss))) return rc;
     Arena ar;
@@ -1183,9 +1438,9 @@ OFLK_API int oflk_warp(const float *image, const float *flow_u, const float *flo
     int rc = check_hw(image, flow_u, H, W);
     if (rc) return rc;
     if (!flow_v || !out) return fail(OFLK_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(g_mu);
-    rc = ensure_device(g_device);
-    if (rc) return rc;
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
     Arena ar;
     size_t n = (size_t)H * W, bytes = n * sizeof(float);
     float *d[4];
@@ -1208,9 +1463,9 @@ OFLK_API int oflk_upsample_flow(const float *flow_u, const float *flow_v, int Hc
     int rc = check_hw(flow_u, flow_v, Hc, Wc);
     if (rc) return rc;
     if ((rc = check_hw(u_out, v_out, Ht, Wt))) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
-    rc = ensure_device(g_device);
-    if (rc) return rc;
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
     Arena ar;
     size_t nc = (size_t)Hc * Wc, nt = (size_t)Ht * Wt;
     float *du = nullptr, *dv = nullptr, *ou = nullptr, *ov = nullptr;

@@ -175,6 +175,27 @@ __device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v)
     *reinterpret_cast<T *>(static_cast<char *>(base) + byte_off) = v;
 }
 
+// Frame pixels are float32 (what the reference's callers hand over) or uint8 (its on-disk frame
+// format, generate_test_suite.py:259-261): PIX selects the element type a kernel reads; the uint8 ->
+// float32 conversion (optical_flow_verifier.py:61-65) is exact, so both give the same values.
+template <class PIX>
+__device__ __forceinline__ float ld_pix(const void *base, unsigned elem)
+{
+    return (float)*reinterpret_cast<const PIX *>(static_cast<const char *>(base) + (size_t)elem * sizeof(PIX));
+}
+// two horizontally adjacent pixels at element offset `elem` (any alignment)
+struct __attribute__((packed)) PairB { unsigned char a, b; };
+template <class PIX>
+__device__ __forceinline__ PairF ld_pix_pair(const void *base, unsigned elem)
+{
+    if constexpr (sizeof(PIX) == 1) {
+        const PairB q = *reinterpret_cast<const PairB *>(static_cast<const char *>(base) + elem);
+        return PairF{(float)q.a, (float)q.b};
+    } else {
+        return ld_off<PairF>(base, elem * 4u);
+    }
+}
+
 __device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx, float u, float v)
 {
     LeanTaps t;
@@ -206,16 +227,18 @@ __device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx,
 }
 
 // NARROW = false: the caller guarantees W >= 2 (and skips the one-column form)
-template <bool NARROW>
-__device__ __forceinline__ void lean_load(const LeanGeom &g, const float *__restrict__ img, const LeanTaps &t,
+template <bool NARROW, class PIX = float>
+__device__ __forceinline__ void lean_load(const LeanGeom &g, const void *__restrict__ img, const LeanTaps &t,
                                           PairF &r0, PairF &r1)
 {
+    // off0 / rowstep are byte offsets of float32 cells: element offsets are a quarter of them
+    const unsigned e0 = t.off0 >> 2, e1 = (t.off0 + g.rowstep) >> 2;
     if (NARROW && g.single) {  // uniform; one-column image: the x+1 tap is the mirrored (same) element, weight 0
-        r0.a = r0.b = ld_off<float>(img, t.off0);
-        r1.a = r1.b = ld_off<float>(img, t.off0 + g.rowstep);
+        r0.a = r0.b = ld_pix<PIX>(img, e0);
+        r1.a = r1.b = ld_pix<PIX>(img, e1);
     } else {
-        r0 = ld_off<PairF>(img, t.off0);
-        r1 = ld_off<PairF>(img, t.off0 + g.rowstep);
+        r0 = ld_pix_pair<PIX>(img, e0);
+        r1 = ld_pix_pair<PIX>(img, e1);
     }
 }
 
@@ -689,9 +712,10 @@ constexpr bool kLkChain = HW <= 2 && MODE != MODE_GRADS;
 #define OFLK_STAMP_OCC
 #endif
 
-template <int HW, int MODE, bool VEC>
+template <int HW, int MODE, bool VEC, class PIX = float>
 __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
 {
+    static_assert(MODE != MODE_GRADS || sizeof(PIX) == 4, "gradient planes are float32");
     static_assert(HW >= 1 && HW <= 5, "windows up to 11x11 (NumPy's single pairwise block)");
     constexpr int R = HW + 1;                              // halo of the frame-average tile
     constexpr int SX = LkGeom<HW>::SX, k5GW = LkGeom<HW>::GW;
@@ -755,8 +779,9 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
         sel = st.executed & 1;
     }
     const size_t plane = (size_t)H * (size_t)W;
-    const float *__restrict__ prev = a.prev + (size_t)b * plane;
-    const float *__restrict__ curr = a.curr + (size_t)b * plane;
+    // frame planes of pair b; PIX-sized elements (a.prev / a.curr are typed float for the common case)
+    const PIX *__restrict__ prev = reinterpret_cast<const PIX *>(a.prev) + (size_t)b * plane;
+    const PIX *__restrict__ curr = reinterpret_cast<const PIX *>(a.curr) + (size_t)b * plane;
     const int x0 = tile_x * k5TX;
     float carry_a[NC], carry_i[NC];
     double blk_u = 0.0, blk_v = 0.0;   // thread 0: |d| sums of the block's tiles
@@ -791,8 +816,8 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                 int gy = y0 - HW + r, gx = x0 - HW + c;
                 bool in = e < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 int i = in ? gy * W + gx : 0;
-                gix[k] = in ? prev[i] : 0.0f;
-                giy[k] = in ? curr[i] : 0.0f;
+                gix[k] = in ? (float)prev[i] : 0.0f;
+                giy[k] = in ? (float)curr[i] : 0.0f;
                 git[k] = in ? gtp[i] : 0.0f;
             }
         } else {
@@ -838,10 +863,10 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                                 const int rr = ((OFLK_G & 4) && (k + 1) * 256 <= ncells) ? r : min(r, AH - 1);   // only the last k runs past the tile
                                 int gy = clamp0(y0 - R + rr, Hm1);  // "symm" ring; farther cells are never used
                                 int gx = clamp0(x0 - R + c, Wm1);
-                                unsigned i = ((unsigned)__mul24(gy, W) + (unsigned)gx) * 4u;
-                                p[k] = ld_off<float>(prev, i);
-                                uu[k] = ld_off<float>(fu_in, i);
-                                vv[k] = ld_off<float>(fv_in, i);
+                                const unsigned ie = (unsigned)__mul24(gy, W) + (unsigned)gx;
+                                p[k] = ld_pix<PIX>(prev, ie);
+                                uu[k] = ld_off<float>(fu_in, ie * 4u);
+                                vv[k] = ld_off<float>(fv_in, ie * 4u);
                                 c += RS; r += QS;
                                 if (c >= AW) { c -= AW; r += 1; }
                             }
@@ -863,7 +888,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                                         int gx = clamp0(x0 - R + c, Wm1);
                                         tp[j] = lean_taps(lg, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
                                         // two 8-byte gathers per cell (the x pair of each tap row)
-                                        lean_load<false>(lg, curr, tp[j], pr0[j], pr1[j]);
+                                        lean_load<false, PIX>(lg, curr, tp[j], pr0[j], pr1[j]);
                                         c += RS; r += QS;
                                         if (c >= AW) { c -= AW; r += 1; }
                                     }
@@ -907,14 +932,22 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                         gx = x0 - SX + 4 * c4;
                         whole = VEC && gx >= 0 && gx + 3 < W;
                     };
-                    auto load4 = [&](const float *__restrict__ src, int gy, int gx, bool whole) -> float4 {
-                        if (whole) return *reinterpret_cast<const float4 *>(src + (unsigned)(gy * W + gx));
-                        const float *row = src + (unsigned)(gy * W);
+                    auto load4 = [&](const PIX *__restrict__ src, int gy, int gx, bool whole) -> float4 {
+                        if (whole) {
+                            if constexpr (sizeof(PIX) == 1) {   // four pixels in one aligned dword
+                                const unsigned q = *reinterpret_cast<const unsigned *>(src + (unsigned)(gy * W + gx));
+                                return make_float4((float)(q & 255u), (float)((q >> 8) & 255u), (float)((q >> 16) & 255u),
+                                                   (float)(q >> 24));
+                            } else {
+                                return *reinterpret_cast<const float4 *>(src + (unsigned)(gy * W + gx));
+                            }
+                        }
+                        const PIX *row = src + (unsigned)(gy * W);
                         float4 r;
-                        r.x = row[min(max(gx, 0), W - 1)];
-                        r.y = row[min(max(gx + 1, 0), W - 1)];
-                        r.z = row[min(max(gx + 2, 0), W - 1)];
-                        r.w = row[min(max(gx + 3, 0), W - 1)];
+                        r.x = (float)row[min(max(gx, 0), W - 1)];
+                        r.y = (float)row[min(max(gx + 1, 0), W - 1)];
+                        r.z = (float)row[min(max(gx + 2, 0), W - 1)];
+                        r.w = (float)row[min(max(gx + 3, 0), W - 1)];
                         return r;
                     };
                     // every coalesced load of the thread's groups goes out first (one HBM latency per tile)
@@ -1019,7 +1052,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
         float pf[3] = {0.0f, 0.0f, 0.0f};
         if (CHAIN && MODE == MODE_ITER && it + 1 < ntile) {
             const int plane_id = tid & 3, slot = tid >> 2;                // 64 threads per plane
-            const float *__restrict__ pl = plane_id == 0 ? prev : plane_id == 1 ? curr
+            const float *__restrict__ pl = plane_id == 0 ? a.prev + (size_t)b * plane : plane_id == 1 ? a.curr + (size_t)b * plane
                                            : (plane_id == 2 ? a.fu[sel] : a.fv[sel]) + (size_t)b * plane;
             constexpr int LPR = 6;                                        // 64-byte lines a 70-cell row may touch
             const unsigned col0 = (unsigned)max(x0 - R, 0) * 4u & ~63u;
@@ -1258,6 +1291,7 @@ struct ResampleArgs {
     Linspace ly, lx;
     int nplanes;          // 1 or 2
     int apply_scale;
+    int vec_store;        // Wo % 4 == 0 and 16-byte aligned outputs: 16-byte stores (host decides)
 };
 
 // One thread produces 4 horizontally adjacent outputs of NP planes: the row taps and
@@ -1321,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
             res[k] = r;
         }
         float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
-        if ((a.Wo & 3) == 0) {
+        if (a.vec_store) {
             *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
         } else {
 #pragma unroll
@@ -1370,6 +1404,7 @@ struct PyrArgs {
     double w[9];       // gaussian weights, w[k] at distance k
 };
 
+template <class PIX>
 __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
 {
     __shared__ float s_in[kPIH * kPIW];   // stage A; reused for the blurred tile (stage C output)
@@ -1381,7 +1416,8 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
     const int H = a.H, W = a.W;
     const size_t ip = (size_t)H * (size_t)W, op = (size_t)a.Ho * (size_t)a.Wo;
     const int img = blockIdx.z;
-    const float *__restrict__ src = img < a.nsplit ? a.in + (size_t)img * ip : a.in2 + (size_t)(img - a.nsplit) * ip;
+    const PIX *__restrict__ src = img < a.nsplit ? reinterpret_cast<const PIX *>(a.in) + (size_t)img * ip
+                                                 : reinterpret_cast<const PIX *>(a.in2) + (size_t)(img - a.nsplit) * ip;
     if (a.zero_words) {
         // grid-stride over all blocks of the launch
         const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
@@ -1415,12 +1451,12 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
         const int r0 = tid / kPIW, c0 = tid - r0 * kPIW;
         float vals[NA];
         if (ybase >= 0 && ybase + kPIH <= H && xbase >= 0 && xbase + kPIW <= W) {
-            unsigned off = ((unsigned)__mul24(ybase + r0, W) + (unsigned)(xbase + c0)) * 4u;
-            const unsigned step = ((unsigned)__mul24(QA, W) + RA) * 4u, wrap = (unsigned)(W - kPIW) * 4u;
+            unsigned off = (unsigned)__mul24(ybase + r0, W) + (unsigned)(xbase + c0);   // element offsets
+            const unsigned step = (unsigned)__mul24(QA, W) + RA, wrap = (unsigned)(W - kPIW);
             int c = c0;
 #pragma unroll
             for (int k = 0; k < NA; k++) {
-                if (k < NA - 1 || tid < NLAST) vals[k] = ld_off<float>(src, off);
+                if (k < NA - 1 || tid < NLAST) vals[k] = ld_pix<PIX>(src, off);
                 off += step; c += RA;
                 if (c >= kPIW) { c -= kPIW; off += wrap; }
             }
@@ -1438,7 +1474,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
                     gy = reflect_idx(gy, H);
                     gx = reflect_idx(gx, W);
                 }
-                if (k < NA - 1 || tid < NLAST) vals[k] = ld_off<float>(src, ((unsigned)__mul24(gy, W) + (unsigned)gx) * 4u);
+                if (k < NA - 1 || tid < NLAST) vals[k] = ld_pix<PIX>(src, (unsigned)__mul24(gy, W) + (unsigned)gx);
                 c += RA; r += QA;
                 if (c >= kPIW) { c -= kPIW; r += 1; }
             }
@@ -1622,7 +1658,7 @@ __global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
-        if ((a.Wo & 3) == 0) {
+        if (a.vec_store) {
             *reinterpret_cast<float4 *>(dst) = make_float4(res[p][0], res[p][1], res[p][2], res[p][3]);
         } else {
 #pragma unroll
@@ -1725,8 +1761,18 @@ struct ExportArgs {
     unsigned long long thr[OFLK_MAX_LEVELS];    // early-exit thresholds as totals
     float *log;                  // [B][L][K][2]
     int *iters_run;              // [B][L]
+    int *uncertain;              // [B][L]: bit k set = the exit decision after iteration k was taken within kDecisionGuard of the threshold
+    unsigned long long guard_lo[OFLK_MAX_LEVELS], guard_hi[OFLK_MAX_LEVELS];   // totals bounding that band
     size_t plane;
 };
+
+// The early-exit test compares np.mean(np.abs(d)) -- an fp32 pairwise sum in 8192-element pieces added
+// up one after the other (error bound ~ pieces x 2^-24 relative) -- with float32(0.01); the device
+// compares an exactly accumulated fixed-point total instead.  The two decisions can only differ when a
+// mean lies within the summation error of the threshold: every decision taken within +-kDecisionGuard
+// (relative) of it is reported, so a caller can tell "provably the reference's decision" from "too
+// close to call" (never seen outside constructed inputs; tests/test_gpu_round2.py builds them).
+constexpr double kDecisionGuard = 5e-5;
 
 // End of a pyramidal call.  (1) Pairs whose finest level exited early hold their result in
 // the internal ping-pong slot: copy it to the caller's buffers.  (2) Block 0 of each pair
@@ -1745,6 +1791,10 @@ __global__ __launch_bounds__(256) void k_export_fixup(ExportArgs a)
             lk_totals(a.acc, b, l, k, a.L, a.K, tu, tv);
             mu = lk_mean_of(tu, a.counts[l]);
             mv = lk_mean_of(tv, a.counts[l]);
+            // decision "both below": it could have gone the other way iff one mean is inside the band
+            // while the other is not clearly above it
+            const bool near_u = tu >= a.guard_lo[l] && tu <= a.guard_hi[l], near_v = tv >= a.guard_lo[l] && tv <= a.guard_hi[l];
+            if ((near_u && tv <= a.guard_hi[l]) || (near_v && tu <= a.guard_hi[l])) atomicOr(&a.uncertain[b * a.L + l], 1 << k);
         }
         const size_t li = (((size_t)b * a.L + l) * a.K + k) * 2;
         a.log[li] = mu;

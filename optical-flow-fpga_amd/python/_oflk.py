@@ -52,6 +52,16 @@ SIGNATURES = {
     "oflk_plan_workspace_bytes": (ctypes.c_size_t, [_vp]),
     "oflk_plan_single_scale": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "oflk_plan_pyramidal": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "oflk_plan_single_scale_u8": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "oflk_plan_pyramidal_u8": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "oflk_single_scale_batch_multi": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
+    "oflk_pyramidal_batch_multi": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
+    "oflk_pyramidal_u8_multi": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
+    "oflk_shard_range": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p]),
+    "oflk_plan_read_uncertain": (ctypes.c_int, [_vp, _i32p, _vp]),
+    "oflk_plan_read_level_flow": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _vp]),
+    "oflk_pyramidal_last_level_flow": (ctypes.c_int, [ctypes.c_int] * 8 + [_f32p, _f32p]),
+    "oflk_pyramidal_last_uncertain": (ctypes.c_int, [ctypes.c_int] * 6 + [_i32p]),
     "oflk_plan_read_log": (ctypes.c_int, [_vp, _f32p, _i32p, _vp]),
     "oflk_plan_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _vp]),
@@ -160,11 +170,30 @@ class Plan:
     def pyramidal(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0) -> None:
         check(lib().oflk_plan_pyramidal(self._h, d_prev, d_curr, d_u, d_v, stream))
 
+    def single_scale_u8(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0) -> None:
+        """d_prev / d_curr: device uint8 frames [B][H][W] (read by the kernels as they are)."""
+        check(lib().oflk_plan_single_scale_u8(self._h, d_prev, d_curr, d_u, d_v, stream))
+
+    def pyramidal_u8(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0) -> None:
+        check(lib().oflk_plan_pyramidal_u8(self._h, d_prev, d_curr, d_u, d_v, stream))
+
     def read_log(self, stream: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         log = np.zeros((self.B, self.levels, max(self.iters, 1), 2), np.float32)
         runs = np.zeros((self.B, self.levels), np.int32)
         check(lib().oflk_plan_read_log(self._h, ptr(log), runs.ctypes.data_as(_i32p), stream))
         return log, runs
+
+    def read_uncertain(self, stream: int = 0) -> np.ndarray:
+        """[B][levels] bit masks: bit k = exit decision after iteration k taken within 5e-5 of the threshold."""
+        m = np.zeros((self.B, self.levels), np.int32)
+        check(lib().oflk_plan_read_uncertain(self._h, m.ctypes.data_as(_i32p), stream))
+        return m
+
+    def read_level_flow(self, level: int, pair: int, shape, stream: int = 0):
+        u = np.empty(shape, np.float32)
+        v = np.empty(shape, np.float32)
+        check(lib().oflk_plan_read_level_flow(self._h, int(level), int(pair), ptr(u), ptr(v), stream))
+        return u, v
 
     def metrics(self, d_u: int, d_v: int, u_true, v_true, region, stream: int = 0) -> np.ndarray:
         """[B][5] = mae_u, mae_v, rmse, epe, aae of device-resident flows over mask[y0:y1, x0:x1]."""

@@ -8,11 +8,15 @@ the progress lines the reference prints (lucas_kanade_pyramidal.py:172-222) are
 reproduced afterwards from the residual log the call returns.
 
 The reference also dumps python/output/pyramid_level_{l}.png from inside the
-function (:226); per-level flow never leaves the device here, so that side effect
-is not reproduced (``visualize_pyramid_level`` itself is kept for callers).
+function (:226), on every call.  Here that side effect is opt-in and best-effort:
+with OFLK_DUMP_LEVELS=1 every level's final flow is read back from the device
+after the call and handed to ``visualize_pyramid_level`` (skipped silently when
+matplotlib is missing); without it nothing leaves the device but the result.
 
-Environment switch (host-side behaviour only, never the arithmetic):
-  OFLK_QUIET=1   suppress the progress lines
+Environment switches (host-side behaviour only, never the arithmetic):
+  OFLK_QUIET=1         suppress the progress lines
+  OFLK_DUMP_LEVELS=1   write python/output/pyramid_level_{l}.png like the reference
+                       (OFLK_DUMP_DIR overrides the directory)
 """
 from __future__ import annotations
 
@@ -148,6 +152,11 @@ def lucas_kanade_pyramidal(
                                                       window_size, num_iterations)
 
     shapes = pyramid_level_shapes(np.shape(frame_prev), num_levels)
+    H, W = int(np.shape(frame_prev)[0]), int(np.shape(frame_prev)[1])
+    key = (1, H, W, int(num_levels), int(window_size), int(num_iterations))
+    # exit decisions taken too close to the 0.01 threshold to be provably the reference's (see oflk.h)
+    flags = np.zeros(max(num_levels, 1), np.int32)
+    _oflk.check(_oflk.lib().oflk_pyramidal_last_uncertain(*key, flags.ctypes.data_as(_i32p)))
     _say(f"Building {num_levels}-level Gaussian pyramids...")
     _say("Pyramid levels:")
     for i, (h, w) in enumerate(shapes):
@@ -161,7 +170,29 @@ def lucas_kanade_pyramidal(
             _say(f"  Iteration {it+1}/{num_iterations}: mean residual = ({mu:.4f}, {mv:.4f})")
             if mu < 0.01 and mv < 0.01:
                 _say(f"  Converged after {it+1} iterations")
+            if int(flags[level]) >> it & 1:
+                _say(f"  note: this residual is within 5e-5 of the 0.01 exit threshold; the reference's fp32 "
+                     f"summation order could decide the other way")
+    if os.environ.get("OFLK_DUMP_LEVELS", "0") == "1":
+        _dump_levels(key, shapes, u, v)
     return u, v
+
+
+def _dump_levels(key, shapes, u, v) -> None:
+    """The reference's per-level PNG side effect (:226), after the call, best-effort."""
+    num_levels = key[3]
+    out_dir = os.environ.get("OFLK_DUMP_DIR", "python/output")
+    try:
+        for level in range(num_levels):
+            if level == num_levels - 1:
+                lu, lv = u, v
+            else:
+                lu = np.empty(shapes[level], np.float32)
+                lv = np.empty(shapes[level], np.float32)
+                _oflk.check(_oflk.lib().oflk_pyramidal_last_level_flow(*key, level, 0, _oflk.ptr(lu), _oflk.ptr(lv)))
+            visualize_pyramid_level(lu, lv, level, num_levels, out_dir)
+    except ImportError:
+        pass  # no matplotlib on this box
 
 
 # ---------------------------------------------------------------------------
