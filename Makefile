@@ -14,6 +14,6 @@ bench:            ## one JSON line (32 pairs of 1080p per step, 3-level pyramida
 	$(PY) bench.py
 
 profiles:         ## regenerate profiles/<tag>_* on the GPU box
-	bash tools/refresh_profiles.sh r01
+	bash tools/refresh_profiles.sh r02
 
 .PHONY: build test test-gpu bench profiles

@@ -5,19 +5,25 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1
 the driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints
 ONE JSON line.
 
-Workload (BASELINE.json configs[2], the config the metric is quoted on): batches
-of independent 1920x1080 frame pairs, 3-level pyramidal LK, 5x5 window, 3
-iterations per level.  One "step" = one pass of the hot path over one batch of
-``--pairs`` synthetic frame pairs per GPU, inputs already resident in HBM.
-Frame pairs are independent units, so ranks share nothing on the data path
-(weak scaling: pairs per GPU fixed); the only collective is the timing MAX.
+Workloads (``--config``):
+  1080p (default)  BASELINE.json configs[2], the config the metric is quoted on: batches of
+                   independent 1920x1080 frame pairs, 3-level pyramidal LK, 5x5 window, 3 iterations per
+                   level; ``--pairs`` pairs per GPU per step, so N GPUs do N times the work ("weak").
+  4k64             BASELINE.json configs[3]: ONE job of 64 pairs of 3840x2160, cut over the ranks with
+                   shard_range(64, rank, N) -- the same job at N = 1/2/4/8 ("strong").
+One "step" = one pass of the hot path over the rank's pairs, inputs already resident in HBM.
+Frame pairs are independent units: ranks share nothing on the data path; the only collectives are
+the barrier of the fence, the MAX of the elapsed time and one SUM of per-rank result totals
+(RCCL, backend "nccl"), all outside or around the timed region (oflk_dist.run_timed).
 
 Extra objects in the JSON line:
-  roofline     -- dominant kernel (fused LK iteration at the finest level):
-                  algorithmic bytes per launch / average launch duration measured
-                  with HIP events on the launch stream during the timed region
-  cpu_baseline -- the CPU oracle (a bit-exact port of the reference's NumPy/SciPy
-                  arithmetic) timed on this host on a bounded sample (N = 1 only)
+  roofline      dominant kernel (fused LK iteration at the finest level): algorithmic bytes per
+                launch / average launch duration from HIP events on the launch stream during the
+                timed region; plus the instruction-side bounds of that kernel (valu_pipe,
+                issue_cadence: tools/issue_bounds.py) when profiles/ holds them for this workload
+  roofline_pyr  the same for the fused pyramid kernel (fp64-bound by SciPy's arithmetic)
+  cpu_baseline  the CPU oracle (a bit-exact port of the reference's NumPy/SciPy arithmetic) timed on
+                this host on a bounded sample (N = 1 only)
 """
 from __future__ import annotations
 
@@ -44,7 +50,22 @@ def algorithmic_bytes_per_pair(dims, levels: int, iters_run) -> dict:
     it = sum(int(iters_run[l]) * 24 * n[l] for l in range(levels))            # prev, curr, u, v in; u, v out
     ups = sum(8 * n[l - 1] + 8 * n[l] for l in range(1, levels))             # u, v coarse in; u, v fine out
     return {"pyramid": pyr, "iterations": it, "upsample": ups, "total": pyr + it + ups,
-            "finest_iteration_launch": 24 * n[-1]}
+            "finest_iteration_launch": 24 * n[-1],
+            "finest_pyramid_launch": (2 * (4 * n[-1] + 4 * n[-2])) if levels > 1 else 0}
+
+
+def profile_file(pattern: str, pairs: int, shape) -> dict | None:
+    """The newest profiles/<tag>_<pattern>.json measured on this workload (PMC passes cannot run inside
+    the bench: tools/measure_traffic.sh, tools/issue_bounds.py)."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob(f"*_{pattern}.json")):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        if d.get("pairs") == pairs and d.get("shape") == list(shape):
+            best = dict(d, _file=f.name)
+    return best
 
 
 def main() -> None:
@@ -52,9 +73,10 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--config", default="1080p", choices=["1080p", "4k64"])
+    ap.add_argument("--pairs", type=int, default=None, help="frame pairs per GPU per step (default: the config's)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--window", type=int, default=5)
     ap.add_argument("--iters", type=int, default=3)
@@ -66,15 +88,14 @@ def main() -> None:
     import numpy as np
     import torch  # first: liboflk then binds to the HIP runtime torch already loaded
 
-    from oflk_dist import Group, env_rank
+    from oflk_dist import Group, env_rank, job_layout, job_throughput, run_timed
 
     rank, local_rank, world = env_rank()
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        # the JSON line must describe the job that was asked for: never continue with another size
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N ranks with torch.distributed.run "
+              f"(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N)", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU path exists)")
     torch.cuda.set_device(local_rank)
@@ -84,16 +105,22 @@ def main() -> None:
     import _oflk
     from oflk_synth import synth_pair
 
-    B, H, W, L, K = args.pairs, args.height, args.width, args.levels, args.iters
-    # a few distinct synthetic pairs per rank, tiled to the batch (different ranks get different pairs)
-    n_distinct = min(B, 4)
-    host = [synth_pair(H, W, pair_index=rank * n_distinct + i) for i in range(n_distinct)]
+    lay = job_layout(args.config, rank, world, args.pairs, args.height, args.width)
+    B, H, W, L, K = lay.pairs_local, lay.height, lay.width, args.levels, args.iters
+    if B < 1:
+        raise SystemExit(f"rank {rank}: no pairs to process ({lay.pairs_total} pairs over {world} ranks)")
+    # a few distinct synthetic pairs, tiled over the job by global pair index (so the job's data does not
+    # depend on how it is cut over the ranks)
+    n_distinct = 4 if H * W <= 1920 * 1080 else 2
+    host = [synth_pair(H, W, pair_index=i) for i in range(n_distinct)]
     prev = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     curr = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    dev_pairs = [(torch.from_numpy(p).to(dev), torch.from_numpy(c).to(dev)) for p, c in host]
     for b in range(B):
-        p, c = host[b % n_distinct]
-        prev[b].copy_(torch.from_numpy(p))
-        curr[b].copy_(torch.from_numpy(c))
+        p, c = dev_pairs[(lay.pair_begin + b) % n_distinct]
+        prev[b].copy_(p)
+        curr[b].copy_(c)
+    del dev_pairs
     u = torch.empty_like(prev)
     v = torch.empty_like(prev)
     plan = _oflk.Plan(local_rank, B, H, W, L, args.window, K)
@@ -102,25 +129,10 @@ def main() -> None:
     def step():
         plan.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
 
-    def fence():
-        torch.cuda.synchronize()
-        group.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
     # timed region: HIP event pairs (on the launch stream) around the dominant kernel only --
     # bracketing all 15 launches of a step costs ~3 % of the step time
-    plan.set_profiling(2)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    fence()
-    elapsed = group.max_over_ranks(elapsed)
+    elapsed = run_timed(group, step, torch.cuda.synchronize, args.steps, args.warmup,
+                        before_timed=lambda: plan.set_profiling(2))
     dom = plan.kernel_times().get("lk_iter_finest", {"total_ms": 0.0, "launches": 0})
     # informational per-kernel breakdown from a few extra, untimed steps with every launch bracketed
     plan.set_profiling(1)
@@ -130,18 +142,18 @@ def main() -> None:
     ktimes = plan.kernel_times()
     plan.set_profiling(0)
     log, runs = plan.read_log(stream)
+    uncertain = int(plan.read_uncertain(stream).astype(bool).sum())
 
-    # job-wide result summary: one small SUM all-reduce (RCCL) of per-rank totals, outside the timed region
-    tot_u = group.sum_over_ranks(float(u.abs().sum(dtype=torch.float64).item()))
-    tot_v = group.sum_over_ranks(float(v.abs().sum(dtype=torch.float64).item()))
-    tot_pairs = int(round(group.sum_over_ranks(float(B))))
-    job_stats = {"pairs_per_step": tot_pairs, "mean_abs_u": round(tot_u / (tot_pairs * H * W), 6),
-                 "mean_abs_v": round(tot_v / (tot_pairs * H * W), 6)}
+    # job-wide figures: pixels of all ranks / MAX-rank time; one SUM all-reduce (RCCL) of per-rank result totals
+    job = job_throughput(group, lay, args.steps, elapsed,
+                         {"abs_u": float(u.abs().sum(dtype=torch.float64).item()),
+                          "abs_v": float(v.abs().sum(dtype=torch.float64).item())})
+    value = job["Mpix_per_s"]
+    npix_job = job["pairs_per_step"] * H * W
+    job_stats = {"pairs_per_step": job["pairs_per_step"], "mean_abs_u": round(job["sums"]["abs_u"] / npix_job, 6),
+                 "mean_abs_v": round(job["sums"]["abs_v"] / npix_job, 6)}
 
-    total_pix = float(world) * B * H * W * args.steps
-    value = total_pix / elapsed / 1e6
-
-    # ---- roofline of the dominant kernel ------------------------------------
+    # ---- roofline of the dominant kernel, and of the pyramid kernel ------------------
     import lucas_kanade_pyramidal as P
 
     dims = P.pyramid_level_shapes((H, W), L)
@@ -151,20 +163,35 @@ def main() -> None:
         avg_ms = dom["total_ms"] / dom["launches"]
         bytes_per_launch = model["finest_iteration_launch"] * B
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from PMC counters are collected by tools/measure_traffic.sh in
-        # separate rocprofv3 passes (they cannot be read live); used when they match this workload
-        traffic = None
-        for f in sorted((ROOT / "profiles").glob("*_hbm_traffic.json")):
-            try:
-                tr = json.loads(f.read_text())
-                if tr.get("pairs") == B and tr.get("shape") == [H, W]:
-                    traffic = tr["hbm_bytes_per_launch"]
-            except Exception:
-                pass
+        tr = profile_file("hbm_traffic", B, (H, W))
+        ib = profile_file("issue_bounds", B, (H, W))
         roofline = {"bound": "hbm", "kernel": "k_lkw<2,ITER> (fused LK iteration, finest level)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": bytes_per_launch}
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                    "traffic_source": (f"profiles/{tr['_file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                                       f"over this command (tools/measure_traffic.sh), not measurable inside the run") if tr else None,
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "hbm_floor_us": round(bytes_per_launch / HBM_PEAK_GBS / 1e3, 1)}
+        if ib:
+            # the instruction-side bounds of the same launch (the kernel's arithmetic is the reference's, op for op)
+            for k in ("valu_pipe", "issue_cadence"):
+                roofline[k] = {"bound": k, "floor_us": ib[k]["floor_us"],
+                               "frac": round(ib[k]["floor_us"] / (avg_ms * 1e3), 4)}
+            roofline["binding"] = ("none saturated: latency-bound at 4 waves per SIMD (wave state shares "
+                                   f"{ib.get('wave_state_shares')}); see DESIGN.md section 5")
+            roofline["issue_bounds_source"] = f"profiles/{ib['_file']} (tools/issue_bounds.py)"
+    roofline_pyr = None
+    pk = ktimes.get("pyr_down_fused")
+    if pk and pk["launches"] and L > 1:
+        # one launch per pyramid step; the finest one (both frames of every pair) carries 80 % of the bytes
+        per_call_ms = (L - 1) * pk["total_ms"] / pk["launches"]   # L-1 launches per call
+        pyr_bytes = algorithmic_bytes_per_pair(dims, L, runs[0])["pyramid"] * B
+        a = pyr_bytes / (per_call_ms * 1e-3) / 1e9
+        roofline_pyr = {"bound": "hbm", "kernel": "k_pyr_down (fused 17-tap blur x2 + linspace resample), all levels of a call",
+                        "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                        "us_per_call": round(per_call_ms * 1e3, 1), "algorithmic_bytes_per_call": pyr_bytes,
+                        "note": "bound by SciPy's fp64 arithmetic (25 fp64 operations per blurred pixel and axis), not by HBM"}
     # whole-call view: algorithmic bytes of the full pyramidal call over step time
     step_bytes = sum(algorithmic_bytes_per_pair(dims, L, runs[b])["total"] for b in range(B))
     whole = {"algorithmic_bytes_per_step": step_bytes,
@@ -198,7 +225,8 @@ def main() -> None:
         import oflk_oracle as O  # checker/baseline only; never on the measured path
 
         O.set_threads(1)
-        n = max(1, args.cpu_sample_pairs)
+        # ~10 s of single-thread work whatever the frame size
+        n = max(1, int(round(args.cpu_sample_pairs * (1080 * 1920) / float(H * W))))
         c0 = time.perf_counter()
         for i in range(n):
             p, c = host[i % n_distinct]
@@ -228,14 +256,17 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": lay.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} frame pairs, {L}-level pyramidal LK, {args.window}x{args.window} window, "
-                                   f"{K} iterations/level", "pairs_per_gpu_per_step": B,
-                       "parallelism": f"frame-pair sharding x{world}", "iterations_run_pair0": [int(x) for x in runs[0]]},
+                                   f"{K} iterations/level", "name": lay.config, "what": lay.label,
+                       "pairs_per_gpu_per_step": B, "pairs_per_step_job": job["pairs_per_step"],
+                       "parallelism": f"frame-pair sharding x{world}", "iterations_run_pair0": [int(x) for x in runs[0]],
+                       "exit_decisions_within_5e-5_of_threshold": uncertain},
             "roofline": roofline,
+            "roofline_pyr": roofline_pyr,
             "whole_call": whole,
             "kernels": kernels,
             "job_stats": job_stats,

@@ -125,6 +125,18 @@ int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *curr, int 
 /* device-side conversion for pipelines that hold uint8 frames in HBM: d_out[i] = (float)d_in[i] */
 int oflk_u8_to_f32(const unsigned char *d_in, float *d_out, size_t n, void *stream);
 
+/* ---- reduced precision (BASELINE config 5), opt-in, never the default ------------ */
+/* lucas_kanade_single_scale with fp16 gradients and fp16 window accumulators: float32 frames in,
+ * float32 flow out, everything between the frame average and the 2x2 solve in half precision, window
+ * sums separable.  This is NOT the reference's arithmetic (python/lucas_kanade_core.py:110-133 is fp32
+ * throughout): results are close to, not equal to, oflk_single_scale_batch -- how close is measured,
+ * per pattern, by tests/test_gpu_fp16.py (mean / median endpoint error against the exact path).
+ *   pixel_max : upper bound of the frame values (255 for the reference's 8-bit frames); frames are
+ *               scaled by a power of two so that a window sum of Ix^2 stays below fp16's 65504.
+ *               Values beyond [0, pixel_max] may overflow to inf / nan. */
+int oflk_single_scale_fp16(const float *prev, const float *curr, int B, int H, int W, int window_size,
+                           float pixel_max, float *u, float *v);
+
 /* ---- one process, several GPUs ------------------------------------------------- */
 /* Frame pairs are independent units (python/lucas_kanade_pyramidal.py:141-228 touches only its two
  * inputs), so a batch shards over GPUs with no data-path exchange: the B pairs are cut into n_gpus
@@ -171,6 +183,9 @@ int oflk_plan_single_scale(oflk_plan *plan, const float *d_prev, const float *d_
                            float *d_u, float *d_v, void *stream);
 int oflk_plan_pyramidal(oflk_plan *plan, const float *d_prev, const float *d_curr, float *d_u,
                         float *d_v, void *stream);
+/* device-resident form of oflk_single_scale_fp16 (any plan; levels / iters are not used) */
+int oflk_plan_single_scale_fp16(oflk_plan *plan, const float *d_prev, const float *d_curr, float *d_u, float *d_v,
+                                float pixel_max, void *stream);
 /* the same passes on device-resident uint8 frames [B][H][W] (see "uint8 frames" above) */
 int oflk_plan_single_scale_u8(oflk_plan *plan, const unsigned char *d_prev, const unsigned char *d_curr,
                               float *d_u, float *d_v, void *stream);

@@ -653,6 +653,48 @@ OFLK_API int oflk_plan_single_scale(oflk_plan *p, const float *d_prev, const flo
     return plan_single_scale(p, d_prev, d_curr, false, d_u, d_v, (hipStream_t)stream);
 }
 
+// BASELINE config 5: fp16 gradients / accumulators (k_lk16).  pixel_max bounds the frame values.
+OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, const float *d_curr, float *d_u, float *d_v,
+                                         float pixel_max, void *stream)
+{
+    if (!p || !d_prev || !d_curr || !d_u || !d_v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    if (!(pixel_max > 0.0f) || !std::isfinite(pixel_max)) return fail(OFLK_ERR_INVALID, "pixel_max must be positive and finite");
+    HIP_TRY(hipSetDevice(p->device));
+    const int hw = p->hw, taps = (2 * hw + 1) * (2 * hw + 1);
+    // s_g = 2^-k, the largest power of two (<= 1) with taps * (pixel_max / 2 * s_g)^2 <= 60000
+    int k = 0;
+    while ((double)taps * std::pow(0.5 * (double)pixel_max * std::ldexp(1.0, -k), 2.0) > 60000.0) k++;
+    Lk16Args a{};
+    a.prev = d_prev; a.curr = d_curr;
+    a.u = d_u; a.v = d_v;
+    a.H = p->H; a.W = p->W; a.B = p->B;
+    a.s_g = (float)std::ldexp(1.0, -k);
+    a.s_t = 0.5f * a.s_g;
+    a.det_thr = (float)(1e-4 * std::ldexp(1.0, -4 * k));
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_x = (a.W + k16TX - 1) / k16TX, tiles_y = (a.H + k16TY - 1) / k16TY;
+    dim3 grid((unsigned)(tiles_x * tiles_y * a.B));
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool vec = (a.W & 3) == 0 && al16(d_prev) && al16(d_curr) && al16(d_u) && al16(d_v);
+    Prof pr(p, s, KC_LK_SINGLE);
+#define OFLK_LAUNCH_LK16(HWV)                                                       \
+    do {                                                                            \
+        if (vec) hipLaunchKernelGGL((k_lk16<HWV, true>), grid, dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((k_lk16<HWV, false>), grid, dim3(256), 0, s, a);     \
+    } while (0)
+    switch (hw) {
+        case 1: OFLK_LAUNCH_LK16(1); break;
+        case 2: OFLK_LAUNCH_LK16(2); break;
+        case 3: OFLK_LAUNCH_LK16(3); break;
+        case 4: OFLK_LAUNCH_LK16(4); break;
+        case 5: OFLK_LAUNCH_LK16(5); break;
+        default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
+    }
+#undef OFLK_LAUNCH_LK16
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
 OFLK_API int oflk_plan_single_scale_u8(oflk_plan *p, const unsigned char *d_prev, const unsigned char *d_curr,
                                        float *d_u, float *d_v, void *stream)
 {
@@ -1181,6 +1223,29 @@ OFLK_API int oflk_pyramidal_u8(const unsigned char *prev, const unsigned char *c
     if (levels < 1) return fail(OFLK_ERR_INVALID, "levels must be in [1,%d] (got %d)", OFLK_MAX_LEVELS, levels);
     return run_batch_on<unsigned char>(g_device.load(), prev, curr, B, H, W, levels, window_size, iters, u, v,
                                        residual_log, iters_run);
+}
+
+OFLK_API int oflk_single_scale_fp16(const float *prev, const float *curr, int B, int H, int W, int window_size,
+                                    float pixel_max, float *u, float *v)
+{
+    int rc = check_hw(prev, curr, H, W);
+    if (rc) return rc;
+    if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
+    oflk_plan *p = nullptr;
+    if ((rc = host_plan(*c, g_device.load(), B, H, W, 1, window_size, 0, &p))) return rc;
+    const size_t n = (size_t)B * H * W, bytes = n * sizeof(float);
+    if ((rc = host_io(*c, n))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->io[0], prev, bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(c->io[1], curr, bytes, hipMemcpyHostToDevice, nullptr));
+    if ((rc = oflk_plan_single_scale_fp16(p, c->io[0], c->io[1], c->io[2], c->io[3], pixel_max, nullptr))) return rc;
+    HIP_TRY(hipMemcpyAsync(u, c->io[2], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, c->io[3], bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
 }
 
 // ---- one process, several GPUs: the batch sharded over devices 0 .. n_gpus-1 ---------------

@@ -58,6 +58,8 @@ SIGNATURES = {
     "oflk_pyramidal_batch_multi": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
     "oflk_pyramidal_u8_multi": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
     "oflk_shard_range": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p]),
+    "oflk_single_scale_fp16": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _f32p, _f32p]),
+    "oflk_plan_single_scale_fp16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp]),
     "oflk_plan_read_uncertain": (ctypes.c_int, [_vp, _i32p, _vp]),
     "oflk_plan_read_level_flow": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _vp]),
     "oflk_pyramidal_last_level_flow": (ctypes.c_int, [ctypes.c_int] * 8 + [_f32p, _f32p]),
@@ -169,6 +171,10 @@ class Plan:
 
     def pyramidal(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0) -> None:
         check(lib().oflk_plan_pyramidal(self._h, d_prev, d_curr, d_u, d_v, stream))
+
+    def single_scale_fp16(self, d_prev: int, d_curr: int, d_u: int, d_v: int, pixel_max: float = 255.0, stream: int = 0) -> None:
+        """BASELINE config 5: fp16 gradients / accumulators (opt-in, approximate)."""
+        check(lib().oflk_plan_single_scale_fp16(self._h, d_prev, d_curr, d_u, d_v, float(pixel_max), stream))
 
     def single_scale_u8(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0) -> None:
         """d_prev / d_curr: device uint8 frames [B][H][W] (read by the kernels as they are)."""

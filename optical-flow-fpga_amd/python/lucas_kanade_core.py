@@ -64,6 +64,20 @@ def lucas_kanade_single_scale(
     return u, v
 
 
+def lucas_kanade_single_scale_fp16(frame_prev, frame_curr, window_size: int = 5, pixel_max: float = 255.0):
+    """Opt-in reduced-precision single-scale flow: fp16 gradients and fp16 window accumulators
+    (BASELINE.json config 5; oflk_single_scale_fp16).  No counterpart in the reference, whose
+    arithmetic is fp32 (lucas_kanade_core.py:110-133): close to ``lucas_kanade_single_scale``,
+    not equal to it (tests/test_gpu_fp16.py reports the endpoint error per pattern)."""
+    p, c = _oflk.as_f32(frame_prev), _oflk.as_f32(frame_curr)
+    H, W = _oflk.same_shape(p, c)
+    u = np.empty((H, W), np.float32)
+    v = np.empty((H, W), np.float32)
+    _oflk.check(_oflk.lib().oflk_single_scale_fp16(_oflk.ptr(p), _oflk.ptr(c), 1, H, W, int(window_size),
+                                                   float(pixel_max), _oflk.ptr(u), _oflk.ptr(v)))
+    return u, v
+
+
 def lucas_kanade_from_gradients(
     Ix: npt.NDArray[np.float32],
     Iy: npt.NDArray[np.float32],

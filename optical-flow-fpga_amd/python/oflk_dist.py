@@ -10,7 +10,9 @@ gather of small per-rank summaries to rank 0.
 from __future__ import annotations
 
 import os
-from typing import Any, List, Optional, Tuple
+import time
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Tuple
 
 
 def env_rank() -> Tuple[int, int, int]:
@@ -79,3 +81,76 @@ class Group:
         if self.dist is not None and self.dist.is_initialized():
             self.dist.destroy_process_group()
             self.dist = None
+
+
+# ---------------------------------------------------------------------------
+# bench.py's job layout and timed region (here so that the CPU tests drive the same code)
+# ---------------------------------------------------------------------------
+CONFIGS: Dict[str, Dict[str, Any]] = {
+    # BASELINE.json configs[2], the config the metric is quoted on: per-GPU work fixed (weak scaling)
+    "1080p": {"height": 1080, "width": 1920, "pairs_per_gpu": 32, "total_pairs": None, "scaling": "weak",
+              "label": "BASELINE configs[2]: 1920x1080 frame pairs, batches per GPU"},
+    # BASELINE.json configs[3]: ONE job of 64 pairs of 3840x2160 cut over the ranks (strong scaling)
+    "4k64": {"height": 2160, "width": 3840, "pairs_per_gpu": None, "total_pairs": 64, "scaling": "strong",
+             "label": "BASELINE configs[3]: 64 frame pairs of 3840x2160 sharded over the GPUs"},
+}
+
+
+@dataclass
+class JobLayout:
+    config: str
+    height: int
+    width: int
+    pairs_local: int      # pairs this rank processes per step
+    pair_begin: int       # index of its first pair in the job
+    pairs_total: int      # pairs of the whole job per step
+    scaling: str          # "weak" | "strong"
+    label: str
+
+
+def job_layout(config: str, rank: int, world: int, pairs_per_gpu: Optional[int] = None,
+               height: Optional[int] = None, width: Optional[int] = None) -> JobLayout:
+    """Which frame pairs a rank owns.  Pairs are independent units: ranks never exchange data."""
+    if config not in CONFIGS:
+        raise ValueError(f"unknown config {config!r} (have {sorted(CONFIGS)})")
+    c = CONFIGS[config]
+    H, W = int(height or c["height"]), int(width or c["width"])
+    if c["scaling"] == "weak":
+        n = int(pairs_per_gpu or c["pairs_per_gpu"])
+        return JobLayout(config, H, W, n, rank * n, world * n, "weak", c["label"])
+    total = int(pairs_per_gpu * world) if pairs_per_gpu else int(c["total_pairs"])
+    b0, b1 = shard_range(total, rank, world)
+    return JobLayout(config, H, W, b1 - b0, b0, total, "strong", c["label"])
+
+
+def run_timed(group: "Group", step: Callable[[], None], device_sync: Callable[[], None], steps: int, warmup: int,
+              before_timed: Optional[Callable[[], None]] = None) -> float:
+    """bench.py's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
+    device-sync + barrier + device-sync on both sides; returns the MAX over ranks of the elapsed seconds."""
+
+    def fence() -> None:
+        device_sync()
+        group.barrier()
+        device_sync()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    if before_timed is not None:
+        before_timed()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    elapsed = time.perf_counter() - t0
+    fence()
+    return group.max_over_ranks(elapsed)
+
+
+def job_throughput(group: "Group", layout: JobLayout, steps: int, elapsed_max: float, local_sums: Dict[str, float]
+                   ) -> Dict[str, Any]:
+    """Whole-job figures on every rank: pixels of ALL ranks / MAX-rank time, and SUM-reduced result totals."""
+    pairs_all = int(round(group.sum_over_ranks(float(layout.pairs_local))))
+    sums = {k: group.sum_over_ranks(float(v)) for k, v in sorted(local_sums.items())}
+    pix = float(pairs_all) * layout.height * layout.width * steps
+    return {"pairs_per_step": pairs_all, "Mpix_per_s": pix / elapsed_max / 1e6, "sums": sums}

@@ -20,6 +20,13 @@ for p in (str(PRODUCT), str(ORACLE), str(ROOT / "tests")):
 
 os.environ.setdefault("OFLK_QUIET", "1")
 
+# torch first (bench.py does the same): liboflk then binds to the HIP runtime torch has already
+# loaded; the other order leaves two runtimes in the process and torch may then see no GPU
+try:
+    import torch  # noqa: F401
+except Exception:  # the CPU suite does not need it
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerate everything under profiles/ for one tag (run on the GPU box from the repo root):
-#   bash tools/refresh_profiles.sh r01
+#   bash tools/refresh_profiles.sh r02
 # 1. bench.py line (default workload)            -> profiles/<tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats of the same -> profiles/<tag>_rocprofv3_kernel_stats.csv
 #                                                    profiles/<tag>_bench_under_rocprof.json
@@ -8,7 +8,7 @@
 # 3. HBM traffic of the dominant kernel (PMC)     -> profiles/<tag>_hbm_traffic.json, <tag>_pmc/
 # 4. SQ issue/wait counters of the LK kernels     -> profiles/<tag>_sq_counters.txt
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 mkdir -p gpurun_out profiles/${TAG}_pmc
 S=$R/gpurun_out/stats_$TAG
@@ -38,6 +38,18 @@ for k in ("fetch", "write"):
 PY
 bash tools/pmc_sq.sh $TAG > gpurun_out/sq_$TAG.log 2>&1
 cp gpurun_out/pmc_$TAG/summary.txt profiles/${TAG}_sq_counters.txt
+# 5. instruction-side bounds of the dominant kernel (needs the ISA: make asm) -> profiles/<tag>_issue_bounds.json
+./tools/ubench/valu_cycles > profiles/${TAG}_valu_cycles.txt 2>&1 || true
+python3 tools/issue_bounds.py gpurun_out/pmc_$TAG profiles/${TAG}_valu_cycles.txt profiles/${TAG}_issue_bounds.json > gpurun_out/issue_$TAG.log 2>&1 || cat gpurun_out/issue_$TAG.log
+# 6. in-kernel timeline of the same launch (diagnostic build)                  -> profiles/<tag>_stamps_timeline.{json,txt}
+if [ -f tools/liboflk_stamps.so ]; then
+  OFLK_LIB=tools/liboflk_stamps.so timeout -k 10 200 python3 tools/stamps.py profiles/${TAG}_stamps_timeline.json > profiles/${TAG}_stamps_timeline.txt 2>&1 || true
+  rm -f profiles/${TAG}_stamps_timeline.raw.npy
+fi
+# 7. every BASELINE config that fits one GPU, and BASELINE configs[3] as one job on this GPU
+python3 tools/measure_configs.py profiles/${TAG}_configs.json > gpurun_out/cfg_$TAG.log 2>&1 || tail -3 gpurun_out/cfg_$TAG.log
+python3 bench.py --config 4k64 --steps 5 --warmup 1 --no-one-pair > gpurun_out/bench_4k64_$TAG.log 2>&1 || tail -3 gpurun_out/bench_4k64_$TAG.log
+grep -h '^{' gpurun_out/bench_4k64_$TAG.log | tail -1 > profiles/${TAG}_bench_4k64_1gpu.json
 # the bench line proper, last so that it sees the fresh traffic file
 python3 bench.py > gpurun_out/bench_$TAG.log 2>&1
 grep -h '^{' gpurun_out/bench_$TAG.log | tail -1 > profiles/${TAG}_bench.json
