@@ -407,3 +407,23 @@ def test_level_flows_read_back_equal_the_oracle(oracle, tmp_path, monkeypatch):
     except ImportError:
         return
     assert sorted(q.name for q in tmp_path.glob("*.png")) == [f"pyramid_level_{l}.png" for l in range(L)]
+
+
+# ---------------------------------------------------------------------------------------------
+# the progress lines the reference prints (lucas_kanade_pyramidal.py:172-222, README.md:258-299)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["translate_small", "no_motion"])
+def test_printed_log_equals_the_reference_stdout(golden_dir, name, capsys, monkeypatch):
+    """tests/golden/reference_stdout.json holds the reference's own stdout (make_golden_stdout.py);
+    the shim reproduces it from the residual log the C call returns, character for character."""
+    import json
+
+    import lucas_kanade_pyramidal as P
+
+    gold = json.loads((golden_dir / "reference_stdout.json").read_text())
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    p, c = z["frame_0"].astype(np.float32), z[f"frame_1__{name}"].astype(np.float32)
+    monkeypatch.setenv("OFLK_QUIET", "0")
+    capsys.readouterr()
+    P.lucas_kanade_pyramidal(p, c, **gold["args"])
+    assert capsys.readouterr().out == gold["stdout"][name]

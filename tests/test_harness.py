@@ -143,3 +143,47 @@ def test_mask_rectangle_of_the_verifier_regions():
     bad[2, 3] = False
     with pytest.raises(ValueError):
         M.mask_rectangle(bad)
+
+
+def test_visualize_flow_parses_dumps_and_plots(tmp_path):
+    """counterpart of the reference's scripts/visualize_flow.py: the `x y u v` dump written by
+    lucas_kanade_reference.export_flow_field_txt round-trips through parse_flow_field, the test-region
+    statistics use the reference's inclusive slice and skip zero vectors, and the 4-panel PNG is written"""
+    import lucas_kanade_reference as LR
+    import visualize_flow as VF
+
+    H, W = 24, 32
+    rng = np.random.default_rng(0)
+    u = rng.normal(2.0, 0.1, (H, W)).astype(np.float32)
+    v = rng.normal(0.0, 0.1, (H, W)).astype(np.float32)
+    u[:2] = 0
+    v[:2] = 0                                   # border rows without flow
+    region = {"x_min": 5, "x_max": 20, "y_min": 1, "y_max": 10}
+    dump = tmp_path / "flow_field.txt"
+    LR.export_flow_field_txt(u, v, dump, W, H, region)
+    x, y, uu, vv, meta = VF.parse_flow_field(str(dump))
+    assert meta == {"width": W, "height": H, "test_x_min": 5, "test_x_max": 20, "test_y_min": 1, "test_y_max": 10}
+    assert len(x) == H * W and np.allclose(uu.reshape(H, W), u, atol=1e-6) and np.allclose(vv.reshape(H, W), v, atol=1e-6)
+    uf, vf, mf = VF.flow_grids(x, y, uu, vv, H, W)
+    st = VF.region_statistics(uu, vv, uf, vf, mf, meta)
+    sl = (slice(1, 11), slice(5, 21))           # inclusive bounds, like the reference (:113-118)
+    keep = np.hypot(uf, vf)[sl] > 0
+    assert st["num_vectors"] == int(keep.sum()) == 9 * 16   # row 1 carries no flow
+    assert abs(st["mean_u"] - uf[sl][keep].mean()) < 1e-12 and abs(st["std_v"] - vf[sl][keep].std()) < 1e-12
+    # no region in the header: statistics over every vector
+    LR.export_flow_field_txt(u, v, dump, W, H, None)
+    x, y, uu, vv, meta = VF.parse_flow_field(str(dump))
+    assert "test_x_min" not in meta
+    st = VF.region_statistics(uu, vv, *VF.flow_grids(x, y, uu, vv, H, W), meta)
+    assert st["num_vectors"] == H * W
+    try:
+        import matplotlib  # noqa: F401
+        from PIL import Image
+    except ImportError:
+        return
+    frame = tmp_path / "frame_00.png"
+    Image.fromarray(rng.integers(0, 256, (H, W), dtype=np.uint8)).save(frame)
+    LR.export_flow_field_txt(u, v, dump, W, H, region)
+    out = tmp_path / "results" / "viz.png"
+    VF.create_diagnostic_plot(str(frame), str(dump), str(out), 2.0, 0.0, stride=7)
+    assert out.exists() and out.stat().st_size > 10_000
