@@ -1569,15 +1569,15 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
 
 // ---------------------------------------------------------------------------
 // K4: upsample_flow (lucas_kanade_pyramidal.py:100-138) with the coarse tile staged in
-// LDS.  A block produces 256 x 4 fine outputs of both planes; the coarse cells it
+// LDS.  A block produces 256 x 16 fine outputs of both planes; the coarse cells it
 // samples (at most kUSW columns x kUSH rows per plane) are fetched with coalesced
 // loads once, and the 16 taps per plane of each thread come from LDS (gathering them
 // from global memory made the kernel L1-throughput bound).  Same arithmetic as
 // k_resample<2> with scaling; the host checks that every block's source span fits
 // (upsample_fits) and falls back to k_resample<2> otherwise.
 // ---------------------------------------------------------------------------
-constexpr int kUTW = 256, kUTH = 4;   // fine outputs per block
-constexpr int kUSW = 136, kUSH = 4;   // coarse columns / rows staged per plane
+constexpr int kUTW = 256, kUTH = 16;  // fine outputs per block: a thread owns 4 (x) by 4 (y) of them
+constexpr int kUSW = 136, kUSH = 10;  // coarse columns / rows staged per plane
 
 __global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
 {
@@ -1598,72 +1598,89 @@ __global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
     if (ib + kUTH >= a.Ho) ylo = min(ylo, max(H - 2, 0));
     if (jb + kUTW >= a.Wo) xlo = min(xlo, max(W - 2, 0));
     {
-        constexpr int NL = (2 * kUSH * kUSW + 255) / 256;  // 5 staged cells per thread
+        // coalesced staging: all loads of a thread are issued before the first LDS write
+        constexpr int NL = (2 * kUSH * kUSW + 255) / 256;  // 11 staged cells per thread
+        constexpr int QS = 256 / kUSW, RS = 256 % kUSW;    // (row, column) advance per 256 cells
         float vals[NL];
+        int r = tid / kUSW, c = tid - r * kUSW;            // row runs over both planes: 2 * kUSH rows
 #pragma unroll
         for (int k = 0; k < NL; k++) {
-            int e = min(tid + k * 256, 2 * kUSH * kUSW - 1);
-            int p = e / (kUSH * kUSW);
-            int rem = e - p * (kUSH * kUSW);
-            int r = rem / kUSW, c = rem - r * kUSW;
-            int gy = min(ylo + r, H - 1), gx = min(xlo + c, W - 1);
-            vals[k] = (a.in[p] + selofs + (size_t)img * ip)[(unsigned)(gy * W + gx)];
+            const int rr = min(r, 2 * kUSH - 1);           // only the last k runs past the tile
+            const int p = rr >= kUSH ? 1 : 0, row = rr - p * kUSH;
+            const int gy = min(ylo + row, H - 1), gx = min(xlo + c, W - 1);
+            vals[k] = ld_off<float>(a.in[p] + selofs + (size_t)img * ip, ((unsigned)__mul24(gy, W) + (unsigned)gx) * 4u);
+            c += RS; r += QS;
+            if (c >= kUSW) { c -= kUSW; r += 1; }
         }
 #pragma unroll
         for (int k = 0; k < NL; k++) {
-            int e = tid + k * 256;
-            if (e < 2 * kUSH * kUSW) (&s_src[0][0][0])[e] = vals[k];
+            const int e = tid + k * 256;
+            if ((k + 1) * 256 <= 2 * kUSH * kUSW || e < 2 * kUSH * kUSW) (&s_src[0][0][0])[e] = vals[k];
         }
     }
     __syncthreads();
 
     const int j0 = jb + (tid & 63) * 4;
-    const int i = ib + (tid >> 6);
-    if (j0 >= a.Wo || i >= a.Ho) return;
+    const int i0 = ib + (tid >> 6) * 4;
+    if (j0 >= a.Wo || i0 >= a.Ho) return;
     // Same sampling as lean_taps (see there): one unsigned compare per axis for the range test,
     // and a sample exactly on the last index is expressed from the cell before it (floor capped at
     // N-2, fraction exactly 1), so the two taps of an axis are always adjacent cells of the staged
-    // tile.  The y side is per thread, the x side per output, the tap arithmetic per plane.
+    // tile.  The x side is computed once per thread and reused by its four rows.
     const LeanGeom lg = lean_geom(H, W);
-    const double y = linspace_at(a.ly, i);
-    const bool y_in = (unsigned long long)__double_as_longlong(y) <= (unsigned long long)__double_as_longlong(lg.Hm1);
-    const double fy = fmin(floor(y), lg.Hm2);
-    const double wy0 = 1.0 - (y - fy), wy1 = 1.0 - wy0;
-    const int row0 = y_in ? (int)fy - ylo : 0;
     const int rstep = H > 1 ? kUSW : 0;           // LDS words from tap row 0 to tap row 1
     const int cstep = W > 1 ? 1 : 0;
-    const float *__restrict__ tile = &s_src[0][0][0];
-    float res[2][4];
+    double wx0[4], wx1[4];
+    int xo[4];
+    bool x_in[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = min(j0 + k, a.Wo - 1);
         const double x = linspace_at(a.lx, j);
-        const bool inside =
-            y_in & ((unsigned long long)__double_as_longlong(x) <= (unsigned long long)__double_as_longlong(lg.Wm1));
+        x_in[k] = (unsigned long long)__double_as_longlong(x) <= (unsigned long long)__double_as_longlong(lg.Wm1);
         const double fx = fmin(floor(x), lg.Wm2);
-        const double wx0 = 1.0 - (x - fx), wx1 = 1.0 - wx0;
-        const int o00 = inside ? row0 * kUSW + ((int)fx - xlo) : 0;
+        wx0[k] = 1.0 - (x - fx);
+        wx1[k] = 1.0 - wx0[k];
+        xo[k] = x_in[k] ? (int)fx - xlo : 0;
+    }
+    const float *__restrict__ tile = &s_src[0][0][0];
+    const bool vec = a.vec_store != 0;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int i = i0 + o;
+        if (i >= a.Ho) break;
+        const double y = linspace_at(a.ly, i);
+        const bool y_in = (unsigned long long)__double_as_longlong(y) <= (unsigned long long)__double_as_longlong(lg.Hm1);
+        const double fy = fmin(floor(y), lg.Hm2);
+        const double wy0 = 1.0 - (y - fy), wy1 = 1.0 - wy0;
+        const int row0 = y_in ? ((int)fy - ylo) * kUSW : 0;
+        float res[2][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool inside = y_in & x_in[k];
+            const int o00 = inside ? row0 + xo[k] : 0;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const float *t = tile + p * (kUSH * kUSW) + o00;
+                double acc, c;
+                c = (double)t[0]; c = c * wy0; acc = c * wx0[k];
+                c = (double)t[cstep]; c = c * wy0; c = c * wx1[k]; acc = acc + c;
+                c = (double)t[rstep]; c = c * wy1; c = c * wx0[k]; acc = acc + c;
+                c = (double)t[rstep + cstep]; c = c * wy1; c = c * wx1[k]; acc = acc + c;
+                const float r = inside ? (float)acc : 0.0f;
+                res[p][k] = r * a.scale[p];   // fp32 multiply by float32(scale), :135-136
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            const float *t = tile + p * (kUSH * kUSW) + o00;
-            double acc, c;
-            c = (double)t[0]; c = c * wy0; acc = c * wx0;
-            c = (double)t[cstep]; c = c * wy0; c = c * wx1; acc = acc + c;
-            c = (double)t[rstep]; c = c * wy1; c = c * wx0; acc = acc + c;
-            c = (double)t[rstep + cstep]; c = c * wy1; c = c * wx1; acc = acc + c;
-            float r = inside ? (float)acc : 0.0f;
-            res[p][k] = r * a.scale[p];   // fp32 multiply by float32(scale), :135-136
-        }
-    }
+            float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
+            if (vec) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(res[p][0], res[p][1], res[p][2], res[p][3]);
+            } else {
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-        float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
-        if (a.vec_store) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(res[p][0], res[p][1], res[p][2], res[p][3]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (j0 + k < a.Wo) dst[k] = res[p][k];
+                for (int k = 0; k < 4; k++)
+                    if (j0 + k < a.Wo) dst[k] = res[p][k];
+            }
         }
     }
 }
