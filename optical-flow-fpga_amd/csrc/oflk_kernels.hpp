@@ -19,7 +19,9 @@
 #pragma clang fp contract(off)
 
 // timing experiments only (tools/ablate.sh): bit 0 no solve, 1 no window adds (LDS reads kept),
-// 2 no window LDS reads either, 3 no fp64 warp arithmetic, 4 no Sobel arithmetic.  Results are wrong.
+// 2 no window LDS reads either, 3 no fp64 warp arithmetic (integer flow), 4 no Sobel arithmetic,
+// 5 flow_out = flow_in (the flow stays 0: identity warp, so the other ablations keep a sane gather pattern),
+// 6 no fp64 tap sums, 7 no fp64 tap coordinates / weights.  Results are wrong.
 #ifndef OFLK_ABLATE
 #define OFLK_ABLATE 0
 #endif
@@ -199,6 +201,12 @@ __device__ __forceinline__ PairF ld_pix_pair(const void *base, unsigned elem)
 __device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx, float u, float v)
 {
     LeanTaps t;
+    if constexpr ((OFLK_ABLATE & 128) != 0) {   // the cell itself: no fp64 at all
+        t.inside = true;
+        t.off0 = ((unsigned)__mul24(min(gy, (int)g.Hm2), g.W) + (unsigned)min(gx, (int)g.Wm2)) * 4u + (u + v == 12345.0f ? 4u : 0u);
+        t.wy0 = t.wy1 = t.wx0 = t.wx1 = 0.0;
+        return t;
+    }
     if constexpr ((OFLK_ABLATE & 8) != 0) {
         const int yy = gy + (int)v, xx = gx + (int)u;
         t.inside = (unsigned)yy < (unsigned)(int)g.Hm1 && (unsigned)xx < (unsigned)(int)g.Wm1;
@@ -246,7 +254,7 @@ __device__ __forceinline__ float lean_finish(const LeanTaps &t, PairF r0, PairF 
 {
     // SciPy starts the sum at +0.0; adding the first term to it only matters for the sign of an
     // all-zero result (-0.0 vs +0.0, equal as values), so the sum starts at the first term
-    if constexpr ((OFLK_ABLATE & 8) != 0) return t.inside ? r0.a + r0.b + r1.a + r1.b : 0.0f;
+    if constexpr ((OFLK_ABLATE & (8 | 64)) != 0) return t.inside ? r0.a + r0.b + r1.a + r1.b : 0.0f;
     double acc, c;
     c = (double)r0.a; c = c * t.wy0; acc = c * t.wx0;
     c = (double)r0.b; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
@@ -1170,6 +1178,11 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                         if (!PRELOAD) {
                             pu[oy] = ld_off<float2>(iu, ofs);
                             pv[oy] = ld_off<float2>(iv, ofs);
+                        }
+                        if constexpr ((OFLK_ABLATE & 32) != 0) {   // d is computed (and kept alive) but not added
+                            asm volatile("" ::"v"(ru.x), "v"(ru.y), "v"(rv.x), "v"(rv.y));
+                            ru = make_float2(0.0f, 0.0f);
+                            rv = make_float2(0.0f, 0.0f);
                         }
                         ru.x = pu[oy].x + ru.x; ru.y = pu[oy].y + ru.y;
                         rv.x = pv[oy].x + rv.x; rv.y = pv[oy].y + rv.y;
