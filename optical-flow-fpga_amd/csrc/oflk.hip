@@ -171,8 +171,7 @@ struct oflk_plan {
     // workspace
     float *pyr[OFLK_MAX_LEVELS] = {nullptr};      // l < L-1: [2B][h][w] (prev then curr)
     float *tmpA = nullptr, *tmpB = nullptr;       // blur temporaries [2B][H][W]
-    // per level one block: [slot 0..1][u, v][B][h][w]; the finest level owns one
-    // slot only (its other slot is the caller's output buffers)
+    // per level one block: [slot 0..1][B][h][w] of interleaved float2 {u, v} (see LkArgs)
     float *flow[OFLK_MAX_LEVELS] = {nullptr};
     // per-call state, one allocation, zeroed by k_call_init at the start of every call:
     //   acc[B][L][K][kAccShards][kAccStride] (u64) | iters_run[B][L] (i32) | uncertain[B][L] (i32) | log[B][L][K][2] (f32)
@@ -195,8 +194,7 @@ struct oflk_plan {
     long acc_n[KC_COUNT] = {0};
 
     size_t npix(int l) const { return (size_t)dims[2 * l] * (size_t)dims[2 * l + 1]; }
-    float *fu(int l, int slot) const { return flow[l] + (size_t)(2 * slot) * B * npix(l); }
-    float *fv(int l, int slot) const { return flow[l] + (size_t)(2 * slot + 1) * B * npix(l); }
+    float2 *fl(int l, int slot) const { return reinterpret_cast<float2 *>(flow[l]) + (size_t)slot * B * npix(l); }
     int Kc() const { return std::max(K, 1); }
     size_t n_acc() const { return (size_t)B * L * Kc() * kAccShards * kAccStride; }
     unsigned long long *acc() const { return state; }
@@ -326,8 +324,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     auto al4 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3u) == 0; };
     const bool frames_ok = u8 ? (al4(a.prev) && al4(a.curr)) : (al16(a.prev) && al16(a.curr));   // uint8: 4 pixels per dword
-    const bool vec = (a.W & 3) == 0 && frames_ok && al16(a.aux) && al16(a.fu[0]) && al16(a.fu[1]) && al16(a.fv[0]) &&
-                     al16(a.fv[1]);
+    const bool vec = (a.W & 3) == 0 && frames_ok && al16(a.aux) && al16(a.fl[0]) && al16(a.fl[1]) && al16(a.ou) && al16(a.ov);
 #define OFLK_LAUNCH_LKW(HWV)                                                                          \
     do {                                                                                              \
         if constexpr (MODE != MODE_GRADS) {                                                           \
@@ -397,8 +394,12 @@ bool upsample_fits(int hc, int wc, int ht, int wt)
 }
 
 // upsample_flow of `nimg` flow fields (both planes); r is fully populated by the caller
-int launch_upsample(oflk_plan *plan, hipStream_t s, const ResampleArgs &r, int nimg)
+int launch_upsample(oflk_plan *plan, hipStream_t s, const ResampleArgs &r_in, int nimg)
 {
+    ResampleArgs r = r_in;
+    // 16-byte stores want Wo % 4 == 0 and 16-byte aligned output planes (hipMalloc / torch give that)
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    r.vec_store = (r.Wo & 3) == 0 && al16(r.out[0]) && (r.interleaved || al16(r.out[1]));
     Prof pr(plan, s, KC_UPSAMPLE);
     if (upsample_fits(r.H, r.W, r.Ho, r.Wo)) {
         dim3 grid((r.Wo + kUTW - 1) / kUTW, (r.Ho + kUTH - 1) / kUTH, nimg);
@@ -494,6 +495,7 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
     r.lx = make_linspace(w, wo);
     r.nplanes = 1;
     r.apply_scale = 0;
+    r.vec_store = (wo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     {
         Prof pr(plan, s, KC_RESAMPLE);
         hipLaunchKernelGGL(k_resample<1>, grid_resample(wo, ho, nimg), dim3(256), 0, s, r);
@@ -584,8 +586,8 @@ OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, 
     *out = nullptr;
     if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
     if (iters < 0) return fail(OFLK_ERR_INVALID, "iters must be >= 0");
-    if ((size_t)H * (size_t)W >= ((size_t)1 << 30) || H >= (1 << 24) || W >= (1 << 24))
-        return fail(OFLK_ERR_UNSUPPORTED, "frames of 2^30 pixels or more are not supported");  // 32-bit byte offsets
+    if ((size_t)H * (size_t)W >= ((size_t)1 << 29) || H >= (1 << 24) || W >= (1 << 24))
+        return fail(OFLK_ERR_UNSUPPORTED, "frames of 2^29 pixels or more are not supported");  // 32-bit byte offsets into float2 planes
     int hw = 0;
     int rc = window_hw(window_size, &hw);
     if (rc) return rc;
@@ -608,9 +610,7 @@ OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, 
     for (int l = 0; l < levels && !rc; l++) {
         size_t n = (size_t)dims[2 * l] * dims[2 * l + 1];
         if (l < levels - 1) rc = dmalloc(&p->pyr[l], 2 * (size_t)B * n, &p->ws_bytes);
-        // finest level: one of the ping-pong buffers is the caller's output
-        int nb = (l == levels - 1) ? 1 : 2;
-        if (!rc) rc = dmalloc(&p->flow[l], (size_t)nb * 2 * B * n, &p->ws_bytes);
+        if (!rc && (iters > 0 || levels > 1)) rc = dmalloc(&p->flow[l], (size_t)2 * 2 * B * n, &p->ws_bytes);   // two interleaved slots
     }
     if (!rc) rc = dmalloc(&p->state, p->state_words() / 2, &p->ws_bytes);
     if (rc) {
@@ -640,7 +640,7 @@ int plan_single_scale(oflk_plan *p, const void *d_prev, const void *d_curr, bool
     LkArgs a{};
     a.prev = static_cast<const float *>(d_prev);   // element type is the kernel's PIX (launch_lk, u8)
     a.curr = static_cast<const float *>(d_curr);
-    a.fu[0] = d_u; a.fv[0] = d_v;
+    a.ou = d_u; a.ov = d_v;
     a.H = p->H; a.W = p->W;
     return launch_lk<MODE_SINGLE>(p, s, KC_LK_SINGLE, p->hw, a, p->B, u8);
 }
@@ -739,27 +739,20 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
     // typed float for the common case; with u8 the kernels of the finest level read them as uint8
     const float *d_prev = static_cast<const float *>(d_prev_in), *d_curr = static_cast<const float *>(d_curr_in);
 
-    // the caller's buffers are the ping-pong slot the final flow lands in when no
-    // level exits early at the finest level: slot K % 2
-    const int want = K & 1;
-    float *fu[OFLK_MAX_LEVELS][2], *fv[OFLK_MAX_LEVELS][2];
-    for (int l = 0; l + 1 < L; l++)
-        for (int i = 0; i < 2; i++) {
-            fu[l][i] = p->fu(l, i);
-            fv[l][i] = p->fv(l, i);
-        }
-    fu[L - 1][want] = d_u;
-    fv[L - 1][want] = d_v;
-    fu[L - 1][1 - want] = p->fu(L - 1, 0);
-    fv[L - 1][1 - want] = p->fv(L - 1, 0);
+    // every level's flow lives in two interleaved {u, v} ping-pong slots of the plan; only the finest
+    // level's last launch writes the caller's planar planes (k_export_fixup de-interleaves the rest)
+    if (!p->flow[0]) {   // a plan created with levels = 1, iters = 0 (single-scale use) asked for a pyramidal pass after all
+        for (int l = 0; l < L; l++)
+            if ((rc = dmalloc(&p->flow[l], (size_t)2 * 2 * B * p->npix(l), &p->ws_bytes))) return rc;
+    }
 
     // per-call state (acc, iters_run, log) = 0 and flow = zeros at the coarsest level (:182-184):
     // carried by the first pyramid launch, or a launch of its own when there is no pyramid
     PyrExtra first;
     first.zero_words = reinterpret_cast<unsigned *>(p->state);
     first.n_zero_words = p->state_words();
-    first.zero_u = fu[0][0];
-    first.zero_v = fv[0][0];
+    first.zero_u = reinterpret_cast<float *>(p->fl(0, 0));   // slot 0 of the coarsest level: 2 * B * n floats
+    first.zero_v = first.zero_u + (size_t)B * p->npix(0);
     first.n_zero_flow = (size_t)B * p->npix(0);
     if (L == 1) {
         rc = launch_call_init(p, s, first);
@@ -791,16 +784,16 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
             // upsample_flow (:195-197) from whichever slot holds level l-1's result
             const int hc = p->dims[2 * (l - 1)], wc = p->dims[2 * (l - 1) + 1];
             ResampleArgs r{};
-            // level l-1 (never the finest) keeps both slots in one block: slot s of
-            // a plane sits s * (2*B*n_c) elements after slot 0
-            r.in[0] = fu[l - 1][0];
-            r.in[1] = fv[l - 1][0];
+            // interleaved planes: slot s of level l-1 sits s * (B*n_c) float2 elements after slot 0
+            r.interleaved = 1;
+            r.in[0] = reinterpret_cast<const float *>(p->fl(l - 1, 0));
+            r.in[1] = nullptr;
             r.acc = p->acc();
             r.acc_level = l - 1; r.L = L; r.K = p->Kc(); r.iters = K;
             r.acc_thr = conv_threshold((double)p->npix(l - 1));
-            r.in_sel_stride = (size_t)2 * B * p->npix(l - 1);
-            r.out[0] = fu[l][0];
-            r.out[1] = fv[l][0];
+            r.in_sel_stride = (size_t)B * p->npix(l - 1);
+            r.out[0] = reinterpret_cast<float *>(p->fl(l, 0));
+            r.out[1] = nullptr;
             r.scale[0] = (float)((double)w / (double)wc);  // scale_x (:123, :135)
             r.scale[1] = (float)((double)h / (double)hc);  // scale_y (:122, :136)
             r.H = hc; r.W = wc; r.Ho = h; r.Wo = w;
@@ -816,8 +809,9 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
         for (int k = 0; k < K; k++) {
             LkArgs a{};
             a.prev = lp; a.curr = lc;
-            a.fu[0] = fu[l][0]; a.fu[1] = fu[l][1];
-            a.fv[0] = fv[l][0]; a.fv[1] = fv[l][1];
+            a.fl[0] = p->fl(l, 0); a.fl[1] = p->fl(l, 1);
+            a.ou = d_u; a.ov = d_v;
+            a.planar_out = (l == L - 1 && k == K - 1) ? 1 : 0;
             a.acc = p->acc();
             a.conv_thr = conv_threshold((double)n);
             a.level = l; a.iter = k; a.L = L; a.K = p->Kc();
@@ -829,12 +823,12 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
     // pairs whose finest level exited early hold their result in the internal slot
     {
         ExportArgs e{};
-        e.src_u = fu[L - 1][1 - want];
-        e.src_v = fv[L - 1][1 - want];
+        e.src[0] = p->fl(L - 1, 0);
+        e.src[1] = p->fl(L - 1, 1);
         e.dst_u = d_u;
         e.dst_v = d_v;
         e.acc = p->acc();
-        e.want = want;
+        e.want = 0;
         e.L = L; e.K = p->Kc(); e.iters = K;
         for (int l = 0; l < L; l++) {
             e.counts[l] = (double)p->npix(l);
@@ -912,9 +906,13 @@ OFLK_API int oflk_plan_read_level_flow(oflk_plan *p, int level, int pair, float 
     HIP_TRY(hipStreamSynchronize(s));
     const int slot = executed & 1;   // the ping-pong slot the level's last executed iteration wrote
     const size_t n = p->npix(level);
-    HIP_TRY(hipMemcpyAsync(u, p->fu(level, slot) + (size_t)pair * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(v, p->fv(level, slot) + (size_t)pair * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    std::vector<float2> both(n);
+    HIP_TRY(hipMemcpyAsync(both.data(), p->fl(level, slot) + (size_t)pair * n, n * sizeof(float2), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++) {   // de-interleave on the host (a debugging / plotting path)
+        u[i] = both[i].x;
+        v[i] = both[i].y;
+    }
     return OFLK_OK;
 }
 
@@ -1453,7 +1451,7 @@ OFLK_API int oflk_from_gradients(const float *Ix, const float *Iy, const float *
     HIP_TRY(hipMemcpyAsync(d[2], It, bytes, hipMemcpyHostToDevice, nullptr));
     LkArgs a{};
     a.prev = d[0]; a.curr = d[1]; a.aux = d[2];
-    a.fu[0] = d[3]; a.fv[0] = d[4];
+    a.ou = d[3]; a.ov = d[4];
     a.H = H; a.W = W;
     rc = launch_lk<MODE_GRADS>(nullptr, nullptr, KC_LK_SINGLE, hw, a, 1);
     if (rc) return rc;

@@ -21,7 +21,8 @@
 // timing experiments only (tools/ablate.sh): bit 0 no solve, 1 no window adds (LDS reads kept),
 // 2 no window LDS reads either, 3 no fp64 warp arithmetic (integer flow), 4 no Sobel arithmetic,
 // 5 flow_out = flow_in (the flow stays 0: identity warp, so the other ablations keep a sane gather pattern),
-// 6 no fp64 tap sums, 7 no fp64 tap coordinates / weights.  Results are wrong.
+// 6 no fp64 tap sums, 7 no fp64 tap coordinates / weights, 8 no gathers of curr (warped = prev),
+// 9 no re-read of the flow in the epilogue, 10 no loads of the flow in stage 1.  Results are wrong.
 #ifndef OFLK_ABLATE
 #define OFLK_ABLATE 0
 #endif
@@ -194,7 +195,11 @@ __device__ __forceinline__ PairF ld_pix_pair(const void *base, unsigned elem)
         const PairB q = *reinterpret_cast<const PairB *>(static_cast<const char *>(base) + elem);
         return PairF{(float)q.a, (float)q.b};
     } else {
+#ifdef OFLK_SPLIT_PAIRS   // experiment: two aligned 4-byte loads instead of one 4-byte-aligned 8-byte load
+        return PairF{ld_off<float>(base, elem * 4u), ld_off<float>(base, elem * 4u + 4u)};
+#else
         return ld_off<PairF>(base, elem * 4u);
+#endif
     }
 }
 
@@ -321,8 +326,14 @@ struct LkArgs {
     const float *prev;  // [B][H][W]   (MODE_GRADS: Ix)
     const float *curr;  // [B][H][W]   (MODE_GRADS: Iy)
     const float *aux;   // MODE_GRADS: It
-    float *fu[2];       // flow ping-pong buffers, [B][H][W]; SINGLE/GRADS write fu[0]
-    float *fv[2];
+    // ITER: the flow of a level lives in two ping-pong slots of INTERLEAVED float2 {u, v} [B][H][W]: one
+    // 8-byte load per staging cell and one 16-byte load / store per output pair instead of twice as many
+    // half as wide (vector-memory instructions are the kernel's scarce resource).
+    // An iteration reads slot `sel` and writes slot 1 - sel, or, when `planar_out` is set (the last
+    // iteration of the finest level), the caller's planar u / v planes.  SINGLE / GRADS write ou / ov.
+    float2 *fl[2];
+    float *ou, *ov;     // planar outputs [B][H][W]
+    int planar_out;
     // ITER: residual accumulators of the whole call, [B][L][K][kAccShards][kAccStride] (see lk_report /
     // lk_level_state); this launch is iteration `iter` of level `level`
     unsigned long long *acc;
@@ -685,11 +696,17 @@ __global__ __launch_bounds__(256) void k_lk_degenerate(LkArgs a)
     if (e < plane) {
         const size_t i = (size_t)b * plane + e;
         if (MODE == MODE_ITER) {
-            a.fu[1 - sel][i] = a.fu[sel][i] + 0.0f;   // flow += d
-            a.fv[1 - sel][i] = a.fv[sel][i] + 0.0f;
+            const float2 f = a.fl[sel][i];
+            const float2 g = make_float2(f.x + 0.0f, f.y + 0.0f);   // flow += d
+            if (a.planar_out) {
+                a.ou[i] = g.x;
+                a.ov[i] = g.y;
+            } else {
+                a.fl[1 - sel][i] = g;
+            }
         } else {
-            a.fu[0][i] = 0.0f;
-            a.fv[0][i] = 0.0f;
+            a.ou[i] = 0.0f;
+            a.ov[i] = 0.0f;
         }
     }
     // d = 0: nothing to add to the accumulators; the iteration reads as converged
@@ -846,8 +863,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             auto stage1 = [&](auto rs) {
                 constexpr int rstart = decltype(rs)::value;
                 if (MODE == MODE_ITER) {
-                    const float *__restrict__ fu_in = a.fu[sel] + (size_t)b * plane;
-                    const float *__restrict__ fv_in = a.fv[sel] + (size_t)b * plane;
+                    const float2 *__restrict__ fl_in = a.fl[sel] + (size_t)b * plane;
                     // Per-cell path (adjacent lanes = adjacent cells, so the bilinear gathers of a
                     // wave touch 2-3 cache lines per instruction).  All coalesced loads of the
                     // thread's cells go out first, then the gathers in batches of BATCH cells.
@@ -873,8 +889,13 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                                 int gx = clamp0(x0 - R + c, Wm1);
                                 const unsigned ie = (unsigned)__mul24(gy, W) + (unsigned)gx;
                                 p[k] = ld_pix<PIX>(prev, ie);
-                                uu[k] = ld_off<float>(fu_in, ie * 4u);
-                                vv[k] = ld_off<float>(fv_in, ie * 4u);
+                                if constexpr ((OFLK_ABLATE & 1024) != 0) {
+                                    uu[k] = vv[k] = 0.0f;
+                                } else {
+                                    const float2 f = ld_off<float2>(fl_in, ie * 8u);
+                                    uu[k] = f.x;
+                                    vv[k] = f.y;
+                                }
                                 c += RS; r += QS;
                                 if (c >= AW) { c -= AW; r += 1; }
                             }
@@ -896,7 +917,12 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                                         int gx = clamp0(x0 - R + c, Wm1);
                                         tp[j] = lean_taps(lg, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
                                         // two 8-byte gathers per cell (the x pair of each tap row)
-                                        lean_load<false, PIX>(lg, curr, tp[j], pr0[j], pr1[j]);
+                                        if constexpr ((OFLK_ABLATE & 256) != 0) {
+                                            pr0[j] = PairF{p[k0 + j], p[k0 + j]};
+                                            pr1[j] = pr0[j];
+                                        } else {
+                                            lean_load<false, PIX>(lg, curr, tp[j], pr0[j], pr1[j]);
+                                        }
                                         c += RS; r += QS;
                                         if (c >= AW) { c -= AW; r += 1; }
                                     }
@@ -1061,7 +1087,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
         if (CHAIN && MODE == MODE_ITER && it + 1 < ntile) {
             const int plane_id = tid & 3, slot = tid >> 2;                // 64 threads per plane
             const float *__restrict__ pl = plane_id == 0 ? a.prev + (size_t)b * plane : plane_id == 1 ? a.curr + (size_t)b * plane
-                                           : (plane_id == 2 ? a.fu[sel] : a.fv[sel]) + (size_t)b * plane;
+                                           : reinterpret_cast<const float *>(a.fl[sel] + (size_t)b * plane) + (plane_id == 3 ? plane : 0);
             constexpr int LPR = 6;                                        // 64-byte lines a 70-cell row may touch
             const unsigned col0 = (unsigned)max(x0 - R, 0) * 4u & ~63u;
 #pragma unroll
@@ -1128,33 +1154,34 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
         OFLK_STAMP(12);   // [12] stage 3: window sums
         const int gxb = x0 + 2 * tx;
         float su = 0.0f, sv = 0.0f;
-        float *__restrict__ ou = a.fu[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
-        float *__restrict__ ov = a.fv[MODE == MODE_ITER ? 1 - sel : 0] + (size_t)b * plane;
-        const float *__restrict__ iu = MODE == MODE_ITER ? a.fu[sel] + (size_t)b * plane : nullptr;
-        const float *__restrict__ iv = MODE == MODE_ITER ? a.fv[sel] + (size_t)b * plane : nullptr;
+        // planar outputs (SINGLE / GRADS always; ITER when this launch delivers the call's result)
+        float *__restrict__ ou = a.ou + (size_t)b * plane;
+        float *__restrict__ ov = a.ov + (size_t)b * plane;
+        // interleaved {u, v} slots (ITER)
+        const float2 *__restrict__ fin = MODE == MODE_ITER ? a.fl[sel] + (size_t)b * plane : nullptr;
+        float2 *__restrict__ fout = MODE == MODE_ITER ? a.fl[1 - sel] + (size_t)b * plane : nullptr;
+        const bool planar = MODE != MODE_ITER || a.planar_out != 0;   // uniform
         // borders stay zero (lucas_kanade_core.py:101-108); the column tests are per thread,
         // the row test per output row
         const bool okx0 = (gxb >= HW) & (gxb < W - HW), okx1 = (gxb + 1 >= HW) & (gxb + 1 < W - HW);
         const int gyb = y0 + NY * ty;
-        // byte offset of the thread's first output inside the plane (a plane is < 4 GiB)
-        unsigned ofs = ((unsigned)__mul24(gyb, W) + (unsigned)gxb) * 4u;
-        const unsigned rowbytes = 4u * (unsigned)W;
-        const bool pairs = VEC || (W & 1) == 0;   // gxb is even: an aligned float2 inside the row
+        // element offset of the thread's first output inside the plane (a plane is < 4 GiB)
+        unsigned oel = (unsigned)__mul24(gyb, W) + (unsigned)gxb;
+        const bool pairs = VEC || (W & 1) == 0;   // gxb is even: two adjacent pixels are one aligned access
         // flow += d (lucas_kanade_pyramidal.py:209-210): the current flow of all the thread's rows is
         // requested before the first solve, so the divisions run under the loads' latency
         // (only where the registers are there: 5x5 window, width a multiple of 4)
-        constexpr bool PRELOAD = MODE == MODE_ITER && HW == 2 && VEC;
-        float2 pu[NY], pv[NY];
+        constexpr bool PRELOAD = MODE == MODE_ITER && HW == 2 && VEC && (OFLK_ABLATE & 512) == 0;
+        float4 pf[NY];   // {u0, v0, u1, v1} of the two pixels
         if (PRELOAD) {
 #pragma unroll
             for (int oy = 0; oy < NY; oy++) {
                 const bool in = gyb + oy < H && gxb < W;
-                pu[oy] = in ? ld_off<float2>(iu, ofs + oy * rowbytes) : make_float2(0.0f, 0.0f);
-                pv[oy] = in ? ld_off<float2>(iv, ofs + oy * rowbytes) : make_float2(0.0f, 0.0f);
+                pf[oy] = in ? ld_off<float4>(fin, (oel + (unsigned)(oy * W)) * 8u) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         }
 #pragma unroll
-        for (int oy = 0; oy < NY; oy++, ofs += rowbytes) {
+        for (int oy = 0; oy < NY; oy++, oel += (unsigned)W) {
             const int gy = gyb + oy;
             const bool oky = (gy >= HW) & (gy < H - HW);
             float du[2], dv[2];
@@ -1175,31 +1202,41 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                     float2 ru = make_float2(du[0], du[1]);
                     float2 rv = make_float2(dv[0], dv[1]);
                     if (MODE == MODE_ITER) {
-                        if (!PRELOAD) {
-                            pu[oy] = ld_off<float2>(iu, ofs);
-                            pv[oy] = ld_off<float2>(iv, ofs);
+                        if constexpr ((OFLK_ABLATE & 512) != 0) {
+                            pf[oy] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        } else if (!PRELOAD) {
+                            pf[oy] = ld_off<float4>(fin, oel * 8u);
                         }
                         if constexpr ((OFLK_ABLATE & 32) != 0) {   // d is computed (and kept alive) but not added
                             asm volatile("" ::"v"(ru.x), "v"(ru.y), "v"(rv.x), "v"(rv.y));
                             ru = make_float2(0.0f, 0.0f);
                             rv = make_float2(0.0f, 0.0f);
                         }
-                        ru.x = pu[oy].x + ru.x; ru.y = pu[oy].y + ru.y;
-                        rv.x = pv[oy].x + rv.x; rv.y = pv[oy].y + rv.y;
+                        ru.x = pf[oy].x + ru.x; ru.y = pf[oy].z + ru.y;
+                        rv.x = pf[oy].y + rv.x; rv.y = pf[oy].w + rv.y;
                     }
-                    st_off<float2>(ou, ofs, ru);
-                    st_off<float2>(ov, ofs, rv);
+                    if (planar) {
+                        st_off<float2>(ou, oel * 4u, ru);
+                        st_off<float2>(ov, oel * 4u, rv);
+                    } else {
+                        st_off<float4>(fout, oel * 8u, make_float4(ru.x, rv.x, ru.y, rv.y));
+                    }
                 } else {
 #pragma unroll
                     for (int o = 0; o < 2; o++) {
                         if (gxb + o < W) {
                             float ru = du[o], rv = dv[o];
                             if (MODE == MODE_ITER) {
-                                ru = ld_off<float>(iu, ofs + 4u * o) + ru;
-                                rv = ld_off<float>(iv, ofs + 4u * o) + rv;
+                                const float2 f = ld_off<float2>(fin, (oel + o) * 8u);
+                                ru = f.x + ru;
+                                rv = f.y + rv;
                             }
-                            st_off<float>(ou, ofs + 4u * o, ru);
-                            st_off<float>(ov, ofs + 4u * o, rv);
+                            if (planar) {
+                                st_off<float>(ou, (oel + o) * 4u, ru);
+                                st_off<float>(ov, (oel + o) * 4u, rv);
+                            } else {
+                                st_off<float2>(fout, (oel + o) * 8u, make_float2(ru, rv));
+                            }
                         }
                     }
                 }
@@ -1305,6 +1342,9 @@ struct ResampleArgs {
     int nplanes;          // 1 or 2
     int apply_scale;
     int vec_store;        // Wo % 4 == 0 and 16-byte aligned outputs: 16-byte stores (host decides)
+    // flow upsample inside a pyramidal call: in[0] / out[0] are INTERLEAVED float2 {u, v} planes
+    // (in_sel_stride then counts float2 elements); 0 = two planar planes each (the standalone entry)
+    int interleaved;
 };
 
 // One thread produces 4 horizontally adjacent outputs of NP planes: the row taps and
@@ -1344,18 +1384,26 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
         wx0[k] = 1.0 - (x - fx);
         wx1[k] = 1.0 - wx0[k];
         const int x1 = (x0 + 1 < W) ? x0 + 1 : (W > 1 ? W - 2 : 0);
+        if (NP == 2 && a.interleaved) {
+            const float2 *__restrict__ src = reinterpret_cast<const float2 *>(a.in[0]) + selofs + (size_t)img * ip;
+            const float2 q0 = src[row0 + (unsigned)x0], q1 = src[row0 + (unsigned)x1], q2 = src[row1 + (unsigned)x0],
+                         q3 = src[row1 + (unsigned)x1];
+            t[0][k][0] = q0.x; t[0][k][1] = q1.x; t[0][k][2] = q2.x; t[0][k][3] = q3.x;
+            t[NP - 1][k][0] = q0.y; t[NP - 1][k][1] = q1.y; t[NP - 1][k][2] = q2.y; t[NP - 1][k][3] = q3.y;
+        } else {
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const float *__restrict__ src = a.in[p] + selofs + (size_t)img * ip;
-            t[p][k][0] = src[row0 + (unsigned)x0];
-            t[p][k][1] = src[row0 + (unsigned)x1];
-            t[p][k][2] = src[row1 + (unsigned)x0];
-            t[p][k][3] = src[row1 + (unsigned)x1];
+            for (int p = 0; p < NP; p++) {
+                const float *__restrict__ src = a.in[p] + selofs + (size_t)img * ip;
+                t[p][k][0] = src[row0 + (unsigned)x0];
+                t[p][k][1] = src[row0 + (unsigned)x1];
+                t[p][k][2] = src[row1 + (unsigned)x0];
+                t[p][k][3] = src[row1 + (unsigned)x1];
+            }
         }
     }
+    float res[NP][4];
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        float res[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             double acc = 0.0, c;
@@ -1365,15 +1413,25 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
             c = (double)t[p][k][3]; c = c * wy1; c = c * wx1[k]; acc = acc + c;
             float r = inside[k] ? (float)acc : 0.0f;
             if (a.apply_scale) r = r * a.scale[p];
-            res[k] = r;
+            res[p][k] = r;
         }
+    }
+    if (NP == 2 && a.interleaved) {
+        float2 *__restrict__ dst = reinterpret_cast<float2 *>(a.out[0]) + (size_t)img * op + (size_t)i * a.Wo + j0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (j0 + k < a.Wo) dst[k] = make_float2(res[0][k], res[NP - 1][k]);
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
         float *__restrict__ dst = a.out[p] + (size_t)img * op + (size_t)i * a.Wo + j0;
         if (a.vec_store) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+            *reinterpret_cast<float4 *>(dst) = make_float4(res[p][0], res[p][1], res[p][2], res[p][3]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (j0 + k < a.Wo) dst[k] = res[k];
+                if (j0 + k < a.Wo) dst[k] = res[p][k];
         }
     }
 }
@@ -1610,7 +1668,29 @@ __global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
     int xlo = (int)floor(linspace_at(a.lx, jb));
     if (ib + kUTH >= a.Ho) ylo = min(ylo, max(H - 2, 0));
     if (jb + kUTW >= a.Wo) xlo = min(xlo, max(W - 2, 0));
-    {
+    if (a.interleaved) {
+        // interleaved {u, v} source: one 8-byte load per cell, split into the two LDS planes
+        constexpr int NL = (kUSH * kUSW + 255) / 256;      // 6 staged cells per thread
+        constexpr int QS = 256 / kUSW, RS = 256 % kUSW;    // (row, column) advance per 256 cells
+        const float2 *__restrict__ src = reinterpret_cast<const float2 *>(a.in[0]) + selofs + (size_t)img * ip;
+        float2 vals[NL];
+        int r = tid / kUSW, c = tid - r * kUSW;
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int gy = min(ylo + min(r, kUSH - 1), H - 1), gx = min(xlo + c, W - 1);
+            vals[k] = ld_off<float2>(src, ((unsigned)__mul24(gy, W) + (unsigned)gx) * 8u);
+            c += RS; r += QS;
+            if (c >= kUSW) { c -= kUSW; r += 1; }
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int e = tid + k * 256;
+            if ((k + 1) * 256 <= kUSH * kUSW || e < kUSH * kUSW) {
+                (&s_src[0][0][0])[e] = vals[k].x;
+                (&s_src[1][0][0])[e] = vals[k].y;
+            }
+        }
+    } else {
         // coalesced staging: all loads of a thread are issued before the first LDS write
         constexpr int NL = (2 * kUSH * kUSW + 255) / 256;  // 11 staged cells per thread
         constexpr int QS = 256 / kUSW, RS = 256 % kUSW;    // (row, column) advance per 256 cells
@@ -1683,6 +1763,18 @@ __global__ __launch_bounds__(256) void k_upsample(ResampleArgs a)
                 const float r = inside ? (float)acc : 0.0f;
                 res[p][k] = r * a.scale[p];   // fp32 multiply by float32(scale), :135-136
             }
+        }
+        if (a.interleaved) {
+            float2 *__restrict__ dst = reinterpret_cast<float2 *>(a.out[0]) + (size_t)img * op + (size_t)i * a.Wo + j0;
+            if (vec) {   // (i * Wo + j0) * 8 bytes is a multiple of 32
+                reinterpret_cast<float4 *>(dst)[0] = make_float4(res[0][0], res[1][0], res[0][1], res[1][1]);
+                reinterpret_cast<float4 *>(dst)[1] = make_float4(res[0][2], res[1][2], res[0][3], res[1][3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (j0 + k < a.Wo) dst[k] = make_float2(res[0][k], res[1][k]);
+            }
+            continue;
         }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -2024,13 +2116,13 @@ __global__ __launch_bounds__(256) void k_u8_to_f32(const unsigned char *__restri
     }
 }
 
-// copy the finest-level flow of pairs whose result did not land in the caller's
-// buffers (early exit changed the ping-pong parity); no-op blocks otherwise
+// de-interleave the finest-level flow of pairs whose result was not written to the caller's planar
+// buffers by the level's last launch (early exit); no-op blocks otherwise
 struct ExportArgs {
-    const float *src_u, *src_v;  // internal buffers [B][H][W]
-    float *dst_u, *dst_v;        // caller's buffers
+    const float2 *src[2];        // the finest level's two interleaved {u, v} slots [B][H][W]
+    float *dst_u, *dst_v;        // caller's planar buffers
     const unsigned long long *acc;
-    int want;                    // buffer index that is the caller's
+    int want;                    // unused (kept for layout)
     int L, K;                    // K: accumulator / log layout (>= 1)
     int iters;                   // iterations launched per level
     double counts[OFLK_MAX_LEVELS];             // H*W per level
@@ -2076,15 +2168,19 @@ __global__ __launch_bounds__(256) void k_export_fixup(ExportArgs a)
         a.log[li] = mu;
         a.log[li + 1] = mv;
     }
-    __shared__ int s_slot;
-    if (threadIdx.x == 0) s_slot = lk_level_state(a.acc, b, a.L - 1, a.iters, a.L, a.K, a.thr[a.L - 1]).executed & 1;
+    // the finest level's last launch (iteration iters-1) writes the caller's planar planes itself; a pair
+    // that left the level earlier (or a plan without iterations) still holds its result in an interleaved slot
+    __shared__ int s_exec;
+    if (threadIdx.x == 0) s_exec = lk_level_state(a.acc, b, a.L - 1, a.iters, a.L, a.K, a.thr[a.L - 1]).executed;
     __syncthreads();
-    if (s_slot == a.want) return;
+    if (a.iters >= 1 && s_exec == a.iters) return;
+    const float2 *__restrict__ src = a.src[s_exec & 1] + (size_t)b * a.plane;
     const size_t base = (size_t)b * a.plane;
     const size_t step = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.plane; i += step) {
-        a.dst_u[base + i] = a.src_u[base + i];
-        a.dst_v[base + i] = a.src_v[base + i];
+        const float2 f = src[i];
+        a.dst_u[base + i] = f.x;
+        a.dst_v[base + i] = f.y;
     }
 }
 
