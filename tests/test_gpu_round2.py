@@ -427,3 +427,16 @@ def test_printed_log_equals_the_reference_stdout(golden_dir, name, capsys, monke
     capsys.readouterr()
     P.lucas_kanade_pyramidal(p, c, **gold["args"])
     assert capsys.readouterr().out == gold["stdout"][name]
+
+
+@pytest.mark.parametrize("sf", [0.6, 0.4, 0.75, 0.3])
+def test_pyramid_other_scale_factors_equal_the_reference(golden_dir, sf):
+    """oflk_build_pyramid away from the default scale factor (unfused blur / resample kernels, Gaussian weights from
+    libm): equal to the reference's own pyramids (tests/golden/pyramid_scales.npz)."""
+    import lucas_kanade_pyramidal as P
+
+    z = np.load(golden_dir / "pyramid_scales.npz")
+    pyr = P.build_gaussian_pyramid(z["image"], 3, scale_factor=sf)
+    assert len(pyr) == 3
+    for l, a in enumerate(pyr):
+        _eq(np.asarray(a, np.float32), z[f"sf{sf}_level{l}"], f"scale {sf} level {l}")

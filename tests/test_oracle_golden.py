@@ -182,3 +182,14 @@ def test_oracle_other_presets_equal_reference(oracle, suite, golden_dir, name, p
     p, c = _pair(z, name)
     u, v = oracle.lucas_kanade_pyramidal(p, c, ref["levels"], ref["window_size"], ref["iterations"])
     assert digest(u) == ref["u_sha256"] and digest(v) == ref["v_sha256"]
+
+
+def test_pyramid_other_scale_factors_equal_the_reference(oracle, golden_dir):
+    """build_gaussian_pyramid with scale_factor 0.6 / 0.4 / 0.75 / 0.3 (sigma = 1 / scale_factor): the oracle takes
+    the Gaussian weights from libm's exp, the reference from NumPy's; tests/golden/pyramid_scales.npz (made by
+    importing the reference, make_golden_scales.py) pins these four: equal value for value."""
+    z = np.load(golden_dir / "pyramid_scales.npz")
+    for sf in (0.6, 0.4, 0.75, 0.3):
+        pyr = oracle.build_gaussian_pyramid(z["image"], 3, sf)
+        for l, a in enumerate(pyr):
+            np.testing.assert_array_equal(a, z[f"sf{sf}_level{l}"])

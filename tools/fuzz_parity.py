@@ -100,6 +100,12 @@ def main():
         gu, gv, glog, gruns = P.lucas_kanade_pyramidal_with_log(a, b, L, win, it)
         eu, ev, elog, eruns = O.lucas_kanade_pyramidal_ex(a, b, L, win, it)
         ok &= list(gruns[:L]) == list(eruns) and same(gu, eu) and same(gv, ev)
+        if kind == 0:      # the same 8-bit frames as uint8 arrays: the kernels read the bytes themselves
+            a8, b8 = a.astype(np.uint8), b.astype(np.uint8)
+            u8, v8 = K.lucas_kanade_single_scale(a8, b8, win)
+            ok &= same(u8, ou) and same(v8, ov)
+            hu, hv, _, hruns = P.lucas_kanade_pyramidal_with_log(a8, b8, L, win, it)
+            ok &= list(hruns[:L]) == list(eruns) and same(hu, eu) and same(hv, ev)
         if not ok:
             bad += 1
             print(f"MISMATCH case {i}: H={H} W={W} win={win} kind={kind} L={L} iters={it} runs gpu={list(gruns[:L])} oracle={list(eruns)}", flush=True)
