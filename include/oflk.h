@@ -203,6 +203,22 @@ int oflk_plan_read_log(oflk_plan *plan, float *residual_log, int *iters_run, voi
  * that band, so 0 everywhere means "provably the reference's iteration counts".  Synchronises. */
 int oflk_plan_read_uncertain(oflk_plan *plan, int *uncertain, void *stream);
 
+/* Closes that band: every pair of the last pass with a flagged decision is redone -- that pair alone, with
+ * the standalone kernels in the reference's own sequence (pyramid, warp, single-scale LK, flow += d,
+ * upsample; value-identical to the fused path) and np.mean(np.abs(d)) evaluated in NumPy's own order
+ * (fp32 pairwise inside 8192-element pieces, the pieces added serially), the exit test taken on the host.
+ * The pair's slices of d_u / d_v, its log, iteration counts and flags are replaced, so afterwards the
+ * whole batch is the reference's result with the reference's iteration counts.  Slow (a host round trip
+ * per iteration) and rare (never seen outside constructed inputs).  d_prev / d_curr are the frames the
+ * pass was given; *resolved (may be NULL) receives the number of pairs redone.  Synchronises.
+ * The host entry points (oflk_pyramidal*, oflk_pyramidal_u8*) do this themselves after every call;
+ * oflk_last_resolved() tells how many pairs the calling thread's last such call redid. */
+int oflk_plan_resolve_uncertain(oflk_plan *plan, const float *d_prev, const float *d_curr, float *d_u, float *d_v,
+                                void *stream, int *resolved);
+int oflk_plan_resolve_uncertain_u8(oflk_plan *plan, const unsigned char *d_prev, const unsigned char *d_curr,
+                                   float *d_u, float *d_v, void *stream, int *resolved);
+int oflk_last_resolved(void);
+
 /* Final flow of a coarser pyramid level (level < levels-1; the finest level's flow is the result) of
  * pair `pair` of the last pass, to host arrays of that level's size -- what the reference hands to
  * visualize_pyramid_level at python/lucas_kanade_pyramidal.py:226.  Synchronises. */

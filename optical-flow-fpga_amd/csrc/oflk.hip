@@ -29,6 +29,7 @@ namespace {
 using namespace oflk;
 
 thread_local std::string t_err;
+thread_local int t_resolved = 0;   // pairs the last host pyramidal call of this thread redid exactly
 
 int fail(int code, const char *fmt, ...)
 {
@@ -179,6 +180,13 @@ struct oflk_plan {
     // uint8 plans only, and only when the fused pyramid kernel cannot take the frames (it always can for
     // scale 0.5 unless a level is tiny): float32 copies of the caller's frames, allocated on first need
     float *u8_stage[2] = {nullptr, nullptr};
+    // scratch of oflk_plan_resolve_uncertain (one pair, unfused, planar), allocated on first use
+    struct Exact {
+        float *pyr[OFLK_MAX_LEVELS] = {nullptr};   // l < L-1: [2][h][w]
+        float *u[OFLK_MAX_LEVELS] = {nullptr}, *v[OFLK_MAX_LEVELS] = {nullptr};
+        float *warped = nullptr, *du = nullptr, *dv = nullptr, *f32[2] = {nullptr, nullptr}, *pieces = nullptr;
+        bool ready = false;
+    } exact;
     GaussW gauss;
 #ifdef OFLK_STAMPS
     unsigned *stamps = nullptr;      // diagnostic build: per-wave section cycle sums of the last finest-level launch
@@ -529,6 +537,11 @@ void plan_free(oflk_plan *p)
     if (p->tmpB) (void)hipFree(p->tmpB);
     if (p->state) (void)hipFree(p->state);
     for (auto &q : p->u8_stage)
+        if (q) (void)hipFree(q);
+    for (int l = 0; l < OFLK_MAX_LEVELS; l++)
+        for (float *q : {p->exact.pyr[l], p->exact.u[l], p->exact.v[l]})
+            if (q) (void)hipFree(q);
+    for (float *q : {p->exact.warped, p->exact.du, p->exact.dv, p->exact.f32[0], p->exact.f32[1], p->exact.pieces})
         if (q) (void)hipFree(q);
 #ifdef OFLK_STAMPS
     if (p->stamps) (void)hipFree(p->stamps);
@@ -883,6 +896,161 @@ OFLK_API long oflk_debug_stamps(oflk_plan *p, unsigned *out, long max_blocks)
 }
 #endif
 
+namespace {
+
+// np.mean(np.abs(d)) of a device plane in NumPy's own summation order (k_np_abs_piece_sums + the serial
+// addition of the pieces, here on the host in fp32; this translation unit is built with -ffp-contract=off)
+int np_mean_abs(oflk_plan *p, const float *d, size_t n, hipStream_t s, float *mean)
+{
+    const size_t pieces = (n + kNpPiece - 1) / kNpPiece;
+    hipLaunchKernelGGL(k_np_abs_piece_sums, dim3((unsigned)((pieces + 63) / 64)), dim3(64), 0, s, d, n, p->exact.pieces);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> h(pieces);
+    HIP_TRY(hipMemcpyAsync(h.data(), p->exact.pieces, pieces * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    volatile float acc = 0.0f;   // every add rounded to fp32, in order
+    for (size_t i = 0; i < pieces; i++) acc = acc + h[i];
+    *mean = (float)((double)acc / (double)n);
+    return OFLK_OK;
+}
+
+// One pair, the reference's own sequence of steps (lucas_kanade_pyramidal.py:173-223) with the standalone
+// kernels -- pyramid, warp, single-scale LK, flow += d, upsample, all value-identical to the fused path --
+// and the exit decision taken on the HOST from NumPy-order means.  Results and log replace pair b's.
+int resolve_pair(oflk_plan *p, int b, const void *d_prev_in, const void *d_curr_in, bool u8, float *d_u, float *d_v, hipStream_t s)
+{
+    const int L = p->L, K = p->K, H = p->H, W = p->W;
+    const size_t N = (size_t)H * W;
+    oflk_plan::Exact &x = p->exact;
+    int rc;
+    if (!x.ready) {
+        size_t tot = 0;
+        for (int l = 0; l < L; l++) {
+            const size_t n = p->npix(l);
+            if (l < L - 1 && (rc = dmalloc(&x.pyr[l], 2 * n, &tot))) return rc;
+            if ((rc = dmalloc(&x.u[l], n, &tot)) || (rc = dmalloc(&x.v[l], n, &tot))) return rc;
+        }
+        if ((rc = dmalloc(&x.warped, N, &tot)) || (rc = dmalloc(&x.du, N, &tot)) || (rc = dmalloc(&x.dv, N, &tot)) ||
+            (rc = dmalloc(&x.f32[0], N, &tot)) || (rc = dmalloc(&x.f32[1], N, &tot)) ||
+            (rc = dmalloc(&x.pieces, (N + kNpPiece - 1) / kNpPiece, &tot)))
+            return rc;
+        p->ws_bytes += tot;
+        x.ready = true;
+    }
+    // the pair's frames as float32 planes
+    const float *fp, *fc;
+    if (u8) {
+        dim3 grid((unsigned)((N + 4095) / 4096));
+        hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, s, static_cast<const unsigned char *>(d_prev_in) + (size_t)b * N, x.f32[0], N);
+        hipLaunchKernelGGL(k_u8_to_f32, grid, dim3(256), 0, s, static_cast<const unsigned char *>(d_curr_in) + (size_t)b * N, x.f32[1], N);
+        HIP_TRY(hipGetLastError());
+        fp = x.f32[0];
+        fc = x.f32[1];
+    } else {
+        fp = static_cast<const float *>(d_prev_in) + (size_t)b * N;
+        fc = static_cast<const float *>(d_curr_in) + (size_t)b * N;
+    }
+    for (int l = L - 2; l >= 0; l--) {
+        const int h = p->dims[2 * (l + 1)], w = p->dims[2 * (l + 1) + 1], ho = p->dims[2 * l], wo = p->dims[2 * l + 1];
+        if (l == L - 2) {
+            PyrExtra two;
+            two.in2 = fc;
+            two.nsplit = 1;
+            rc = launch_pyr_down(nullptr, p->gauss, s, fp, x.pyr[l], p->tmpA, p->tmpB, 2, h, w, ho, wo, &two);
+        } else {
+            rc = launch_pyr_down(nullptr, p->gauss, s, x.pyr[l + 1], x.pyr[l], p->tmpA, p->tmpB, 2, h, w, ho, wo);
+        }
+        if (rc) return rc;
+    }
+    std::vector<float> log((size_t)L * p->Kc() * 2, 0.0f);
+    std::vector<int> runs((size_t)L, 0);
+    HIP_TRY(hipMemsetAsync(x.u[0], 0, p->npix(0) * sizeof(float), s));   // flow = zeros at the coarsest level (:182-184)
+    HIP_TRY(hipMemsetAsync(x.v[0], 0, p->npix(0) * sizeof(float), s));
+    for (int l = 0; l < L; l++) {
+        const int h = p->dims[2 * l], w = p->dims[2 * l + 1];
+        const size_t n = (size_t)h * w;
+        if (l > 0) {
+            const int hc = p->dims[2 * (l - 1)], wc = p->dims[2 * (l - 1) + 1];
+            ResampleArgs r{};
+            r.in[0] = x.u[l - 1]; r.in[1] = x.v[l - 1];
+            r.out[0] = x.u[l]; r.out[1] = x.v[l];
+            r.scale[0] = (float)((double)w / (double)wc);
+            r.scale[1] = (float)((double)h / (double)hc);
+            r.H = hc; r.W = wc; r.Ho = h; r.Wo = w;
+            r.ly = make_linspace(hc, h);
+            r.lx = make_linspace(wc, w);
+            r.nplanes = 2;
+            r.apply_scale = 1;
+            if ((rc = launch_upsample(nullptr, s, r, 1))) return rc;
+        }
+        const float *lp = (l == L - 1) ? fp : x.pyr[l];
+        const float *lc = (l == L - 1) ? fc : x.pyr[l] + n;
+        for (int k = 0; k < K; k++) {
+            hipLaunchKernelGGL(k_warp, grid2d(w, h, 1), dim3(256), 0, s, lc, (const float *)x.u[l], (const float *)x.v[l], x.warped, h, w);
+            HIP_TRY(hipGetLastError());
+            LkArgs a{};
+            a.prev = lp; a.curr = x.warped;
+            a.ou = x.du; a.ov = x.dv;
+            a.H = h; a.W = w;
+            if ((rc = launch_lk<MODE_SINGLE>(nullptr, s, KC_LK_SINGLE, p->hw, a, 1))) return rc;
+            hipLaunchKernelGGL(k_flow_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x.u[l], x.v[l], (const float *)x.du,
+                               (const float *)x.dv, n);
+            HIP_TRY(hipGetLastError());
+            float mu, mv;
+            if ((rc = np_mean_abs(p, x.du, n, s, &mu)) || (rc = np_mean_abs(p, x.dv, n, s, &mv))) return rc;
+            log[((size_t)l * p->Kc() + k) * 2] = mu;
+            log[((size_t)l * p->Kc() + k) * 2 + 1] = mv;
+            runs[(size_t)l] = k + 1;
+            if (mu < 0.01f && mv < 0.01f) break;   // :221-223
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_u + (size_t)b * N, x.u[L - 1], N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_v + (size_t)b * N, x.v[L - 1], N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // the pair's log, iteration counts and (cleared) flags in the plan's state, where read_log looks
+    HIP_TRY(hipMemcpyAsync(p->log() + (size_t)b * L * p->Kc() * 2, log.data(), log.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(p->iters_run() + (size_t)b * L, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(p->uncertain() + (size_t)b * L, 0, (size_t)L * sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));   // log / runs are host vectors
+    return OFLK_OK;
+}
+
+int resolve_uncertain(oflk_plan *p, const void *d_prev, const void *d_curr, bool u8, float *d_u, float *d_v, hipStream_t s,
+                      int *resolved)
+{
+    if (!p || !d_prev || !d_curr || !d_u || !d_v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<int> flags((size_t)p->B * p->L);
+    HIP_TRY(hipMemcpyAsync(flags.data(), p->uncertain(), flags.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int n = 0;
+    for (int b = 0; b < p->B; b++) {
+        bool any = false;
+        for (int l = 0; l < p->L; l++) any = any || flags[(size_t)b * p->L + l] != 0;
+        if (!any) continue;
+        int rc = resolve_pair(p, b, d_prev, d_curr, u8, d_u, d_v, s);
+        if (rc) return rc;
+        n++;
+    }
+    if (resolved) *resolved = n;
+    return OFLK_OK;
+}
+
+}  // namespace
+
+OFLK_API int oflk_plan_resolve_uncertain(oflk_plan *p, const float *d_prev, const float *d_curr, float *d_u, float *d_v,
+                                         void *stream, int *resolved)
+{
+    return resolve_uncertain(p, d_prev, d_curr, false, d_u, d_v, (hipStream_t)stream, resolved);
+}
+
+OFLK_API int oflk_plan_resolve_uncertain_u8(oflk_plan *p, const unsigned char *d_prev, const unsigned char *d_curr, float *d_u,
+                                            float *d_v, void *stream, int *resolved)
+{
+    return resolve_uncertain(p, d_prev, d_curr, true, d_u, d_v, (hipStream_t)stream, resolved);
+}
+
+OFLK_API int oflk_last_resolved(void) { return t_resolved; }
+
 OFLK_API int oflk_plan_read_uncertain(oflk_plan *p, int *uncertain, void *stream)
 {
     if (!p || !uncertain) return fail(OFLK_ERR_INVALID, "NULL argument");
@@ -1112,6 +1280,8 @@ int run_batch_on(int dev, const PIXELS *prev, const PIXELS *curr, int B, int H, 
     rc = single ? plan_single_scale(p, dp, dc, U8, c->io[2], c->io[3], nullptr)
                 : plan_pyramidal(p, dp, dc, U8, c->io[2], c->io[3], nullptr);
     if (rc) return rc;
+    // exit decisions the device could not take with certainty are redone in NumPy's own summation order
+    if (!single && iters > 0 && (rc = resolve_uncertain(p, dp, dc, U8, c->io[2], c->io[3], nullptr, &t_resolved))) return rc;
     HIP_TRY(hipMemcpyAsync(u, c->io[2], obytes, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipMemcpyAsync(v, c->io[3], obytes, hipMemcpyDeviceToHost, nullptr));
     if (single) {

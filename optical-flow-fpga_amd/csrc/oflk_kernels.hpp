@@ -2185,6 +2185,58 @@ __global__ __launch_bounds__(256) void k_export_fixup(ExportArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Exact residual means for the rare exit decision taken too close to the threshold (kDecisionGuard):
+// np.mean(np.abs(d)) as NumPy evaluates it (lucas_kanade_pyramidal.py:213-214) -- an fp32 pairwise sum
+// (eight strided accumulators per block of <= 128 elements, blocks combined by halving) inside
+// 8192-element pieces of the flat array, the pieces added up one after the other, then
+// float32(float64(sum) / n).  One thread per piece (this is a slow path: host-driven, one pair at a
+// time, oflk_plan_resolve_uncertain); the pieces are added on the host in order.
+// ---------------------------------------------------------------------------
+constexpr int kNpPiece = 8192;   // np.getbufsize()
+
+__device__ __noinline__ float np_pairwise_abs_sum(const float *a, size_t n)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (size_t i = 0; i < n; i++) res = res + fabsf(a[i]);
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        size_t i;
+        for (int j = 0; j < 8; j++) r[j] = fabsf(a[j]);
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] = r[j] + fabsf(a[i + j]);
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res = res + fabsf(a[i]);
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_abs_sum(a, n2) + np_pairwise_abs_sum(a + n2, n - n2);
+}
+
+__global__ __launch_bounds__(64) void k_np_abs_piece_sums(const float *__restrict__ d, size_t n, float *__restrict__ out)
+{
+    const size_t c = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t begin = c * kNpPiece;
+    if (begin >= n) return;
+    const size_t m = n - begin < (size_t)kNpPiece ? n - begin : (size_t)kNpPiece;
+    out[c] = np_pairwise_abs_sum(d + begin, m);
+}
+
+// flow += d (lucas_kanade_pyramidal.py:209-210), planar, for the same slow path
+__global__ __launch_bounds__(256) void k_flow_add(float *__restrict__ fu, float *__restrict__ fv, const float *__restrict__ du,
+                                                  const float *__restrict__ dv, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        fu[i] = fu[i] + du[i];
+        fv[i] = fv[i] + dv[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // F1: masked flow metrics on the device (python/flow_metrics.py:14-201) for the rectangular
 // test regions the verifier uses (mask[y0:y1, x0:x1] = True, optical_flow_verifier.py:96-138),
 // so that a batch run need not copy flow fields to the host.

@@ -60,6 +60,9 @@ SIGNATURES = {
     "oflk_shard_range": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p]),
     "oflk_single_scale_fp16": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _f32p, _f32p]),
     "oflk_plan_single_scale_fp16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp]),
+    "oflk_plan_resolve_uncertain": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
+    "oflk_plan_resolve_uncertain_u8": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
+    "oflk_last_resolved": (ctypes.c_int, []),
     "oflk_plan_read_uncertain": (ctypes.c_int, [_vp, _i32p, _vp]),
     "oflk_plan_read_level_flow": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _vp]),
     "oflk_pyramidal_last_level_flow": (ctypes.c_int, [ctypes.c_int] * 8 + [_f32p, _f32p]),
@@ -194,6 +197,13 @@ class Plan:
         m = np.zeros((self.B, self.levels), np.int32)
         check(lib().oflk_plan_read_uncertain(self._h, m.ctypes.data_as(_i32p), stream))
         return m
+
+    def resolve_uncertain(self, d_prev: int, d_curr: int, d_u: int, d_v: int, stream: int = 0, u8: bool = False) -> int:
+        """Redo the pairs whose exit decisions were flagged, in NumPy's summation order; returns how many."""
+        n = ctypes.c_int(0)
+        fn = lib().oflk_plan_resolve_uncertain_u8 if u8 else lib().oflk_plan_resolve_uncertain
+        check(fn(self._h, d_prev, d_curr, d_u, d_v, stream, ctypes.byref(n)))
+        return int(n.value)
 
     def read_level_flow(self, level: int, pair: int, shape, stream: int = 0):
         u = np.empty(shape, np.float32)

@@ -318,17 +318,11 @@ def test_4k_batch_of_8_matches_oracle(oracle):
 # ---------------------------------------------------------------------------------------------
 # early-exit decisions next to the threshold
 # ---------------------------------------------------------------------------------------------
-def test_exit_decisions_next_to_the_threshold(oracle):
-    """Frames curr_t = prev + t * (shifted - prev): the residual means grow with t.  Bisect t (on the
-    oracle) to the point where the first iteration's larger mean crosses float32(0.01) at the coarsest
-    level, then run the GPU on a ladder of t values around it.  Required: wherever the GPU does not
-    flag the decision as uncertain it took the oracle's iteration counts; far from the threshold
-    (relative distance > 1e-3) nothing may be flagged; and the ladder does reach into the band."""
-    import lucas_kanade_pyramidal as P
-    import _oflk
+def _threshold_family(oracle, H=96, W=128, L=2, K=3):
+    """Frames curr_t = prev + t * (shifted - prev): the residual means grow with t.  Bisect t (on the oracle) to
+    the point where the first iteration's larger mean crosses float32(0.01) at the coarsest level."""
     from oflk_synth import synth_pair
 
-    H, W, L, K = 96, 128, 2, 3
     prev, shifted = synth_pair(H, W, 0, dx=0.75, dy=-0.5)
     delta = (shifted - prev).astype(np.float64)
 
@@ -349,27 +343,76 @@ def test_exit_decisions_next_to_the_threshold(oracle):
             lo = mid
         else:
             hi = mid
-    # ladder: the crossing itself (both sides) and relative offsets out to 3e-2
+    return frames, first_means, lo, hi, thr
+
+
+def test_exit_decisions_next_to_the_threshold(oracle):
+    """A ladder of inputs around the crossing (both sides, relative offsets 1e-7 ... 3e-2).  The device decides
+    from an exact fixed-point total, the reference from an fp32 pairwise sum: they can differ only inside the
+    guard band, where the decision is flagged and the host entry point redoes the pair in NumPy's own order
+    (oflk_plan_resolve_uncertain).  Required: EVERY input takes the oracle's iteration counts, log and flow;
+    inputs further than 1e-3 from the threshold are never redone; the ladder does reach the band."""
+    import lucas_kanade_pyramidal as P
+    import _oflk
+
+    H, W, L, K = 96, 128, 2, 3
+    frames, first_means, lo, hi, thr = _threshold_family(oracle, H, W, L, K)
     ts = [lo, hi]
     for rel in (1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 1e-4, 1e-3, 1e-2, 3e-2):
         ts += [lo * (1 - rel), hi * (1 + rel)]
-    in_band = 0
+    redone = 0
     for t in ts:
         p, c = frames(t)
         m, oruns = first_means(t)
         u, v, log, runs = P.lucas_kanade_pyramidal_with_log(p, c, L, 5, K)
+        n = int(_oflk.lib().oflk_last_resolved())
+        rel_dist = abs(m / thr - 1.0)
+        if n:
+            redone += 1
+            assert rel_dist < 1e-3, f"t={t!r}: redone although the mean {m!r} is {rel_dist:.2e} away from the threshold"
         flags = np.zeros(L, np.int32)
         _oflk.check(_oflk.lib().oflk_pyramidal_last_uncertain(1, H, W, L, 5, K, flags.ctypes.data_as(i32p)))
-        rel_dist = abs(m / thr - 1.0)
-        if flags.any():
-            in_band += 1
-            assert rel_dist < 1e-3, f"t={t!r}: flagged although the mean {m!r} is {rel_dist:.2e} away from the threshold"
-        else:
-            assert list(runs) == oruns, f"t={t!r}: mean {m!r}, GPU ran {list(runs)}, oracle {oruns}, not flagged"
-            ou, ov, _, _ = oracle.lucas_kanade_pyramidal_ex(p, c, L, 5, K)
-            _eq(u, ou, f"t={t!r} u")
-            _eq(v, ov, f"t={t!r} v")
-    assert in_band >= 2, "the ladder never reached the uncertainty band: the construction is broken"
+        assert not flags.any()   # resolved pairs are no longer flagged
+        ou, ov, olog, _ = oracle.lucas_kanade_pyramidal_ex(p, c, L, 5, K)
+        assert list(runs) == oruns, f"t={t!r}: mean {m!r}, GPU ran {list(runs)}, oracle {oruns}"
+        _eq(u, ou, f"t={t!r} u")
+        _eq(v, ov, f"t={t!r} v")
+        if n:   # a redone pair carries NumPy-order means: equal, not merely close
+            for l in range(L):
+                np.testing.assert_array_equal(log[l, :oruns[l]], olog[l, :oruns[l]])
+    assert redone >= 2, "the ladder never reached the uncertainty band: the construction is broken"
+
+
+def test_resolve_uncertain_inside_a_batch(oracle):
+    """Plan API: one near-threshold pair among ordinary ones; only that pair is redone, every pair ends up
+    equal to the oracle; uint8 form included."""
+    import torch
+
+    import _oflk
+    from oflk_synth import synth_pair
+
+    H, W, L, K = 96, 128, 2, 3
+    frames, first_means, lo, hi, thr = _threshold_family(oracle, H, W, L, K)
+    pairs = [synth_pair(H, W, 1), frames(lo), synth_pair(H, W, 2), frames(hi)]
+    dev = torch.device("cuda", 0)
+    prev = torch.from_numpy(np.stack([p for p, _ in pairs])).to(dev)
+    curr = torch.from_numpy(np.stack([c for _, c in pairs])).to(dev)
+    u, v = torch.empty_like(prev), torch.empty_like(prev)
+    plan = _oflk.Plan(0, 4, H, W, L, 5, K)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+    flags = plan.read_uncertain(st)
+    assert flags[1].any() and flags[3].any() and not flags[0].any() and not flags[2].any()
+    assert plan.resolve_uncertain(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), st) == 2
+    assert not plan.read_uncertain(st).any()
+    log, runs = plan.read_log(st)
+    hu, hv = u.cpu().numpy(), v.cpu().numpy()
+    for b, (p, c) in enumerate(pairs):
+        ou, ov, olog, oruns = oracle.lucas_kanade_pyramidal_ex(p, c, L, 5, K)
+        _eq(hu[b], ou, f"pair {b} u")
+        _eq(hv[b], ov, f"pair {b} v")
+        assert list(runs[b]) == list(oruns)
+    plan.close()
 
 
 # ---------------------------------------------------------------------------------------------
