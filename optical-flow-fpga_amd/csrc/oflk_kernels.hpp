@@ -29,6 +29,9 @@
 #ifndef OFLK_G
 #define OFLK_G 14
 #endif
+#ifndef OFLK_PRELOAD_AT
+#define OFLK_PRELOAD_AT 1
+#endif
 #ifndef OFLK_L2_PREFETCH
 #define OFLK_L2_PREFETCH 0
 #endif
@@ -1129,11 +1132,28 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                 row[2 * j + 1] = qv.y;
             }
         };
+        // flow += d (lucas_kanade_pyramidal.py:209-210) needs the current flow of the thread's outputs: requested
+        // OFLK_PRELOAD_AT: 0 = just before the first solve, 1 = before the sums of the last (scalar) plane, where the
+        // register pressure of the float2 planes is gone -- the loads then have that plane's sums and the
+        // divisions to arrive (only where the registers are there: 5x5 window, width a multiple of 4)
+        constexpr bool PRELOAD = MODE == MODE_ITER && HW == 2 && VEC && (OFLK_ABLATE & 512) == 0;
+        float4 pf[NY];   // {u0, v0, u1, v1} of the two pixels
+        auto preload = [&]() {
+            const float2 *__restrict__ fin0 = a.fl[sel] + (size_t)b * plane;
+            const int gx_ = x0 + 2 * tx, gy_ = y0 + NY * ty;
+            const unsigned oel0 = (unsigned)__mul24(gy_, W) + (unsigned)gx_;
+#pragma unroll
+            for (int oy = 0; oy < NY; oy++) {
+                const bool in = gy_ + oy < H && gx_ < W;
+                pf[oy] = in ? ld_off<float4>(fin0, (oel0 + (unsigned)(oy * W)) * 8u) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        };
         if constexpr (HW == 2) {
             const float2 *ba = &s_pa[(NY * ty) * PW + 2 * tx];
             patch5_sums<Sum2, NY>([&](int i, Sum2 (&row)[6]) { load_f2(ba + i * PW, row); }, sA);
             const float2 *bb = &s_pb[(NY * ty) * PW + 2 * tx];
             patch5_sums<Sum2, NY>([&](int i, Sum2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
+            if constexpr (PRELOAD && OFLK_PRELOAD_AT == 1) preload();
             const float *bc = &s_pc[(NY * ty) * PW + 2 * tx];
             patch5_sums<float, NY>([&](int i, float (&row)[6]) { load_f1(bc + i * PW, row); }, sC);
         } else {
@@ -1168,18 +1188,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
         // element offset of the thread's first output inside the plane (a plane is < 4 GiB)
         unsigned oel = (unsigned)__mul24(gyb, W) + (unsigned)gxb;
         const bool pairs = VEC || (W & 1) == 0;   // gxb is even: two adjacent pixels are one aligned access
-        // flow += d (lucas_kanade_pyramidal.py:209-210): the current flow of all the thread's rows is
-        // requested before the first solve, so the divisions run under the loads' latency
-        // (only where the registers are there: 5x5 window, width a multiple of 4)
-        constexpr bool PRELOAD = MODE == MODE_ITER && HW == 2 && VEC && (OFLK_ABLATE & 512) == 0;
-        float4 pf[NY];   // {u0, v0, u1, v1} of the two pixels
-        if (PRELOAD) {
-#pragma unroll
-            for (int oy = 0; oy < NY; oy++) {
-                const bool in = gyb + oy < H && gxb < W;
-                pf[oy] = in ? ld_off<float4>(fin, (oel + (unsigned)(oy * W)) * 8u) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
+        if constexpr (PRELOAD && !(HW == 2 && OFLK_PRELOAD_AT == 1)) preload();
 #pragma unroll
         for (int oy = 0; oy < NY; oy++, oel += (unsigned)W) {
             const int gy = gyb + oy;
