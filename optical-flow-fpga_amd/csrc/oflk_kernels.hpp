@@ -26,15 +26,6 @@
 #ifndef OFLK_ABLATE
 #define OFLK_ABLATE 0
 #endif
-#ifndef OFLK_G
-#define OFLK_G 14
-#endif
-#ifndef OFLK_PRELOAD_AT
-#define OFLK_PRELOAD_AT 1
-#endif
-#ifndef OFLK_L2_PREFETCH
-#define OFLK_L2_PREFETCH 0
-#endif
 
 namespace oflk {
 
@@ -198,11 +189,7 @@ __device__ __forceinline__ PairF ld_pix_pair(const void *base, unsigned elem)
         const PairB q = *reinterpret_cast<const PairB *>(static_cast<const char *>(base) + elem);
         return PairF{(float)q.a, (float)q.b};
     } else {
-#ifdef OFLK_SPLIT_PAIRS   // experiment: two aligned 4-byte loads instead of one 4-byte-aligned 8-byte load
-        return PairF{ld_off<float>(base, elem * 4u), ld_off<float>(base, elem * 4u + 4u)};
-#else
-        return ld_off<PairF>(base, elem * 4u);
-#endif
+        return ld_off<PairF>(base, elem * 4u);   // (two aligned 4-byte loads instead were measured: +6 %)
     }
 }
 
@@ -855,7 +842,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
                     int qi = tid + j * 256;
-                    if (((OFLK_G & 1) && (j + 1) * 256 <= NCARRY) || qi < NCARRY) {   // only the last j is partial: no mask juggling for the others
+                    if (qi < NCARRY) {   // (the mask-free form of the other guards costs this loop's kernel a register too many)
                         s_avg[qi] = carry_a[j];
                         s_it[qi] = carry_i[j];
                     }
@@ -887,7 +874,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     #pragma unroll
                         for (int k = 0; k < NE; k++) {
                             if (k * 256 < ncells) {  // uniform: cell k exists for some thread
-                                const int rr = ((OFLK_G & 4) && (k + 1) * 256 <= ncells) ? r : min(r, AH - 1);   // only the last k runs past the tile
+                                const int rr = (k + 1) * 256 <= ncells ? r : min(r, AH - 1);   // only the last k runs past the tile
                                 int gy = clamp0(y0 - R + rr, Hm1);  // "symm" ring; farther cells are never used
                                 int gx = clamp0(x0 - R + c, Wm1);
                                 const unsigned ie = (unsigned)__mul24(gy, W) + (unsigned)gx;
@@ -915,7 +902,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     #pragma unroll
                                 for (int j = 0; j < BATCH; j++) {
                                     if (k0 + j < NE && (k0 + j) * 256 < ncells) {
-                                        const int rr = ((OFLK_G & 4) && (k0 + j + 1) * 256 <= ncells) ? r : min(r, AH - 1);
+                                        const int rr = (k0 + j + 1) * 256 <= ncells ? r : min(r, AH - 1);
                                         int gy = clamp0(y0 - R + rr, Hm1);
                                         int gx = clamp0(x0 - R + c, Wm1);
                                         tp[j] = lean_taps(lg, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
@@ -947,7 +934,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     #pragma unroll
                         for (int k = 0; k < NE; k++) {
                             if (k * 256 < ncells) {
-                                if (((OFLK_G & 2) && (k + 1) * 256 <= ncells) || r < AH) {   // cell k exists for every thread unless it is the last
+                                if ((k + 1) * 256 <= ncells || r < AH) {   // cell k exists for every thread unless it is the last
                                     float sum = p[k] + q[k];
                                     s_avg[r * AS + c + SC] = sum * 0.5f;
                                     s_it[r * AS + c + SC] = p[k] - q[k];
@@ -1057,7 +1044,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
                     int qi = tid + j * 256;
-                    if (((OFLK_G & 1) && (j + 1) * 256 <= NCARRY) || qi < NCARRY) {
+                    if (qi < NCARRY) {
                         carry_a[j] = s_avg[k5TY * AS + qi];
                         carry_i[j] = s_it[k5TY * AS + qi];
                     }
@@ -1071,7 +1058,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             int e = tid + k * 256;
-            if (((OFLK_G & 8) && (k + 1) * 256 <= PH * PW) || e < PH * PW) {   // only the last k is partial
+            if ((k + 1) * 256 <= PH * PW || e < PH * PW) {   // only the last k is partial
                 float ix = gix[k], iy = giy[k], itv = git[k];
                 s_pa[e] = make_float2(ix * ix, iy * iy);
                 s_pb[e] = make_float2(ix * iy, ix * itv);
@@ -1082,29 +1069,6 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
         __syncthreads();
         OFLK_STAMP(11);   // [11] barrier 3
 
-#if OFLK_L2_PREFETCH
-        // Pull the next chained tile's new staging rows (prev, flow u / v, and the same rows of curr)
-        // towards this XCD's L2 while stage 3 computes: one 4-byte load per 64-byte line, results
-        // consumed (by nothing) at the end of the tile.  Speed only.
-        float pf[3] = {0.0f, 0.0f, 0.0f};
-        if (CHAIN && MODE == MODE_ITER && it + 1 < ntile) {
-            const int plane_id = tid & 3, slot = tid >> 2;                // 64 threads per plane
-            const float *__restrict__ pl = plane_id == 0 ? a.prev + (size_t)b * plane : plane_id == 1 ? a.curr + (size_t)b * plane
-                                           : reinterpret_cast<const float *>(a.fl[sel] + (size_t)b * plane) + (plane_id == 3 ? plane : 0);
-            constexpr int LPR = 6;                                        // 64-byte lines a 70-cell row may touch
-            const unsigned col0 = (unsigned)max(x0 - R, 0) * 4u & ~63u;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int idx = slot + 64 * k;
-                if (idx < k5TY * LPR) {
-                    const int rr = idx / LPR, ll = idx - rr * LPR;
-                    const int gy = min(y0 + k5TY + R + rr, H - 1);
-                    const unsigned colb = min(col0 + 64u * ll, (unsigned)(W - 1) * 4u);
-                    pf[k] = ld_off<float>(pl, (unsigned)__mul24(gy, W) * 4u + colb);
-                }
-            }
-        }
-#endif
         // ---- stage 3: window sums in NumPy order (pk over plane pairs), solve, write -----
         // thread = 2 (x) by NY (y) outputs; a half-wave spans one tile row, so the
         // 16-byte LDS reads of 32 adjacent lanes are contiguous (conflict-free)
@@ -1133,9 +1097,9 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             }
         };
         // flow += d (lucas_kanade_pyramidal.py:209-210) needs the current flow of the thread's outputs: requested
-        // OFLK_PRELOAD_AT: 0 = just before the first solve, 1 = before the sums of the last (scalar) plane, where the
-        // register pressure of the float2 planes is gone -- the loads then have that plane's sums and the
-        // divisions to arrive (only where the registers are there: 5x5 window, width a multiple of 4)
+        // before the sums of the last (scalar) plane, where the register pressure of the float2 planes is gone --
+        // the loads then have that plane's sums and the divisions to arrive (only where the registers are there:
+        // 5x5 window, width a multiple of 4; otherwise just before their use)
         constexpr bool PRELOAD = MODE == MODE_ITER && HW == 2 && VEC && (OFLK_ABLATE & 512) == 0;
         float4 pf[NY];   // {u0, v0, u1, v1} of the two pixels
         auto preload = [&]() {
@@ -1153,7 +1117,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             patch5_sums<Sum2, NY>([&](int i, Sum2 (&row)[6]) { load_f2(ba + i * PW, row); }, sA);
             const float2 *bb = &s_pb[(NY * ty) * PW + 2 * tx];
             patch5_sums<Sum2, NY>([&](int i, Sum2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
-            if constexpr (PRELOAD && OFLK_PRELOAD_AT == 1) preload();
+            if constexpr (PRELOAD) preload();
             const float *bc = &s_pc[(NY * ty) * PW + 2 * tx];
             patch5_sums<float, NY>([&](int i, float (&row)[6]) { load_f1(bc + i * PW, row); }, sC);
         } else {
@@ -1188,7 +1152,6 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
         // element offset of the thread's first output inside the plane (a plane is < 4 GiB)
         unsigned oel = (unsigned)__mul24(gyb, W) + (unsigned)gxb;
         const bool pairs = VEC || (W & 1) == 0;   // gxb is even: two adjacent pixels are one aligned access
-        if constexpr (PRELOAD && !(HW == 2 && OFLK_PRELOAD_AT == 1)) preload();
 #pragma unroll
         for (int oy = 0; oy < NY; oy++, oel += (unsigned)W) {
             const int gy = gyb + oy;
@@ -1263,9 +1226,6 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                 s_red[1][tid >> 6] = (double)sv;
             }
         }
-#if OFLK_L2_PREFETCH
-        asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]));
-#endif
         OFLK_STAMP(13);   // [13] solve, flow += d, stores, |d| reduction
         // stage 3 has read the planes (the next tile's staging overwrites them) and s_red is complete
         if (MODE == MODE_ITER || (CHAIN && it + 1 < ntile)) __syncthreads();
