@@ -83,6 +83,10 @@ def main() -> None:
     ap.add_argument("--cpu-sample-pairs", type=int, default=16, help="1080p pairs the CPU oracle is timed on (~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-pair", action="store_true", help="skip the informational batch-of-1 timing")
+    # rehearsal switches (a one-GPU box cannot host two RCCL ranks): gloo for the three small collectives, and
+    # every rank on one device -- exercises the N > 1 code path end to end; the numbers of such a run mean nothing
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--force-device", type=int, default=None, help="use this GPU on every rank (rehearsal only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -98,9 +102,12 @@ def main() -> None:
         sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU path exists)")
+    if args.force_device is not None:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    group = Group("nccl", dev)  # backend "nccl" is RCCL on ROCm; no-op for one rank
+    # backend "nccl" is RCCL on ROCm (device tensors); gloo reduces host tensors; no-op for one rank
+    group = Group(args.backend, dev if args.backend == "nccl" else None)
 
     import _oflk
     from oflk_synth import synth_pair
@@ -259,7 +266,7 @@ def main() -> None:
             "scaling": lay.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if args.backend == "nccl" and args.force_device is None else "synthetic (REHEARSAL: not a measurement)",
             "config": {"workload": f"{W}x{H} frame pairs, {L}-level pyramidal LK, {args.window}x{args.window} window, "
                                    f"{K} iterations/level", "name": lay.config, "what": lay.label,
                        "pairs_per_gpu_per_step": B, "pairs_per_step_job": job["pairs_per_step"],

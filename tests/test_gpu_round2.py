@@ -483,3 +483,37 @@ def test_pyramid_other_scale_factors_equal_the_reference(golden_dir, sf):
     assert len(pyr) == 3
     for l, a in enumerate(pyr):
         _eq(np.asarray(a, np.float32), z[f"sf{sf}_level{l}"], f"scale {sf} level {l}")
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py with N > 1 ranks, end to end (rehearsal: gloo for the three small collectives, every rank on GPU 0)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("config,ranks,expect_pairs", [("1080p", 2, 6), ("4k64", 3, 64)])
+def test_bench_multi_rank_rehearsal(config, ranks, expect_pairs):
+    """A one-GPU box cannot host two RCCL ranks, so the N > 1 path of bench.py (sharding, per-rank plans on
+    LOCAL_RANK, fence, MAX of the elapsed time, SUM of the result totals, rank-0 JSON) is rehearsed with
+    --backend gloo --force-device 0 on small frames.  The driver's 8-GPU run uses the same code with nccl."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr",
+           "127.0.0.1", "--master-port", "29581" if config == "1080p" else "29582", str(root / "bench.py"), "--gpus", str(ranks),
+           "--steps", "2", "--warmup", "1", "--backend", "gloo", "--force-device", "0", "--config", config, "--height", "120",
+           "--width", "160", "--no-cpu-baseline", "--no-one-pair"]
+    if config == "1080p":
+        cmd += ["--pairs", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == ranks and j["steps"] == 2 and j["warmup"] == 1
+    assert j["scaling"] == ("weak" if config == "1080p" else "strong")
+    assert j["config"]["pairs_per_step_job"] == expect_pairs
+    assert j["job_stats"]["pairs_per_step"] == expect_pairs
+    # whole-job value: pixels of ALL ranks over the MAX-rank time
+    assert abs(j["value"] - expect_pairs * 120 * 160 * 2 / (j["ms_per_step"] * 2e-3) / 1e6) <= 1e-3 * j["value"]
+    assert "REHEARSAL" in j["data"] and j["cpu_baseline"] is None
