@@ -320,10 +320,10 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         if (plan->stamps_blocks < nblocks) {
             if (plan->stamps) (void)hipFree(plan->stamps);
             plan->stamps = nullptr;
-            HIP_TRY(hipMalloc((void **)&plan->stamps, (size_t)nblocks * 512 * sizeof(unsigned)));
+            HIP_TRY(hipMalloc((void **)&plan->stamps, (size_t)nblocks * 520 * sizeof(unsigned)));
             plan->stamps_blocks = nblocks;
         }
-        HIP_TRY(hipMemsetAsync(plan->stamps, 0, (size_t)nblocks * 512 * sizeof(unsigned), s));
+        HIP_TRY(hipMemsetAsync(plan->stamps, 0, (size_t)nblocks * 520 * sizeof(unsigned), s));
         a.stamps = plan->stamps;
     }
 #endif
@@ -685,11 +685,43 @@ OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, cons
     a.s_t = 0.5f * a.s_g;
     a.det_thr = (float)(1e-4 * std::ldexp(1.0, -4 * k));
     hipStream_t s = (hipStream_t)stream;
+    Prof pr(p, s, KC_LK_SINGLE);
+    const bool tiled = getenv("OFLK_LK16_TILED") != nullptr;   // development switch: the LDS-tiled form (k_lk16)
+    if (!tiled) {
+        // streaming form: one wave per (strip of 64 - 2R output columns, segment of Hs rows).  Segments are sized
+        // so that the launch is a whole number of rounds of the chip's 8192 wave slots (256 CUs x 4 SIMDs x 8),
+        // with ~64 rows each (a segment pays 2R extra rows of loads).
+        Lk16sArgs g{};
+        g.prev = d_prev; g.curr = d_curr; g.u = d_u; g.v = d_v;
+        g.H = a.H; g.W = a.W; g.B = a.B;
+        g.s_g = a.s_g; g.s_t = a.s_t; g.det_thr = a.det_thr;
+        const int outw = 64 - 2 * (hw + 1);
+        const long strips = ((long)a.W + outw - 1) / outw * a.B;
+        const long slots = 8192;
+        long segs = ((long)a.H + 63) / 64;
+        const double rounds = (double)(strips * segs) / (double)slots;
+        if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
+        segs = std::min<long>(segs, std::max<long>(1, a.H / 8));
+        if (const char *e = getenv("OFLK_LK16_HS")) segs = std::max<long>(1, ((long)a.H + atol(e) - 1) / std::max<long>(1, atol(e)));
+        g.Hs = (int)(((long)a.H + segs - 1) / segs);
+        g.segs = (a.H + g.Hs - 1) / g.Hs;
+        const long nwave = strips * g.segs;
+        dim3 sgrid((unsigned)((nwave + 3) / 4)), sblock(256);
+        switch (hw) {
+            case 1: hipLaunchKernelGGL((k_lk16s<1>), sgrid, sblock, 0, s, g); break;
+            case 2: hipLaunchKernelGGL((k_lk16s<2>), sgrid, sblock, 0, s, g); break;
+            case 3: hipLaunchKernelGGL((k_lk16s<3>), sgrid, sblock, 0, s, g); break;
+            case 4: hipLaunchKernelGGL((k_lk16s<4>), sgrid, sblock, 0, s, g); break;
+            case 5: hipLaunchKernelGGL((k_lk16s<5>), sgrid, sblock, 0, s, g); break;
+            default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
+        }
+        HIP_TRY(hipGetLastError());
+        return OFLK_OK;
+    }
     const int tiles_x = (a.W + k16TX - 1) / k16TX, tiles_y = (a.H + k16TY - 1) / k16TY;
     dim3 grid((unsigned)(tiles_x * tiles_y * a.B));
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool vec = (a.W & 3) == 0 && al16(d_prev) && al16(d_curr) && al16(d_u) && al16(d_v);
-    Prof pr(p, s, KC_LK_SINGLE);
 #define OFLK_LAUNCH_LK16(HWV)                                                       \
     do {                                                                            \
         if (vec) hipLaunchKernelGGL((k_lk16<HWV, true>), grid, dim3(256), 0, s, a);  \
@@ -892,6 +924,18 @@ OFLK_API long oflk_debug_stamps(oflk_plan *p, unsigned *out, long max_blocks)
     (void)hipDeviceSynchronize();
     const long n = std::min<long>((long)p->stamps_blocks, max_blocks);
     if (out && hipMemcpy(out, p->stamps, (size_t)n * 512 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)p->stamps_blocks;
+}
+
+// [blocks][8]: entry, loop start, loop end, exit on the 100 MHz chip-wide clock; HW_ID; XCC_ID; tiles; valid
+OFLK_API long oflk_debug_block_times(oflk_plan *p, unsigned *out, long max_blocks)
+{
+    if (!p || !p->stamps) return 0;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    const long n = std::min<long>((long)p->stamps_blocks, max_blocks);
+    if (out && hipMemcpy(out, p->stamps + (size_t)p->stamps_blocks * 512, (size_t)n * 8 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
     return (long)p->stamps_blocks;
 }
 #endif

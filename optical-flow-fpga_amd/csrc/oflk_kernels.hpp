@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 
 #include "../../include/oflk.h"
 #include <stdint.h>
@@ -23,6 +24,12 @@
 // 5 flow_out = flow_in (the flow stays 0: identity warp, so the other ablations keep a sane gather pattern),
 // 6 no fp64 tap sums, 7 no fp64 tap coordinates / weights, 8 no gathers of curr (warped = prev),
 // 9 no re-read of the flow in the epilogue, 10 no loads of the flow in stage 1.  Results are wrong.
+#ifndef OFLK_LK16_ABL
+#define OFLK_LK16_ABL 0   // timing experiments on k_lk16s (wrong results): 1 no horizontal shifts, 2 no solve, 4 no stores, 8 no vertical sums, 16 no Sobel shifts
+#endif
+#ifndef OFLK_LK16_PF
+#define OFLK_LK16_PF 2   // rows of frame loads in flight per wave (k_lk16s)
+#endif
 #ifndef OFLK_ABLATE
 #define OFLK_ABLATE 0
 #endif
@@ -758,6 +765,11 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     // rows (frame average, It) that a tile shares with the tile below it are carried over in
     // registers instead of being recomputed: the exact fp64 warp, the dominant cost, runs on
     // 24 new rows per tile instead of 30.
+#ifdef OFLK_STAMPS
+    // block lifetime on the chip-wide 100 MHz clock: entry, tile loop start / end, exit; plus where it ran
+    unsigned bt[4];
+    bt[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     const int H = a.H, W = a.W;
     const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
     // windows above 5x5 run one tile per block: their sum stage needs the registers the loop
@@ -806,6 +818,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     int st_tile = 0;
     for (int i = threadIdx.x; i < 4 * 8 * 16; i += 256) (&s_st[0][0][0])[i] = 0u;
     __syncthreads();
+    bt[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
 
     for (int it = 0; it < (CHAIN ? ntile : 1); it++) {
@@ -1235,10 +1248,23 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             blk_v += (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
         }
     }
+#ifdef OFLK_STAMPS
+    bt[2] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     if (MODE == MODE_ITER && threadIdx.x == 0) lk_report(a, b, blk_u, blk_v);
 #ifdef OFLK_STAMPS
     __syncthreads();
     if (a.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the report's atomics have been issued and acknowledged
+        bt[3] = (unsigned)__builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            unsigned *o = a.stamps + (size_t)gridDim.x * 512 + (size_t)blockIdx.x * 8;
+            o[0] = bt[0]; o[1] = bt[1]; o[2] = bt[2]; o[3] = bt[3];
+            o[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave, simd, pipe, cu, sh, se ...
+            o[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
+            o[6] = (unsigned)ntile;
+            o[7] = 1u;
+        }
         if (threadIdx.x < 4) s_st[threadIdx.x][0][15] = (unsigned)ntile;
         __syncthreads();
         for (int i = threadIdx.x; i < 4 * 8 * 16; i += 256) a.stamps[(size_t)blockIdx.x * 512 + i] = (&s_st[0][0][0])[i];
@@ -1490,6 +1516,10 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
         const int ybase = ylo - 8, xbase = xlo - 8;
         const int r0 = tid / kPIW, c0 = tid - r0 * kPIW;
         float vals[NA];
+        if constexpr ((OFLK_ABLATE & 4096) != 0) {   // timing experiment: no global loads
+#pragma unroll
+            for (int k = 0; k < NA; k++) vals[k] = (float)(tid + k);
+        } else
         if (ybase >= 0 && ybase + kPIH <= H && xbase >= 0 && xbase + kPIW <= W) {
             unsigned off = (unsigned)__mul24(ybase + r0, W) + (unsigned)(xbase + c0);   // element offsets
             const unsigned step = (unsigned)__mul24(QA, W) + RA, wrap = (unsigned)(W - kPIW);
@@ -1538,11 +1568,12 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
             }
 #pragma unroll
             for (int o = 0; o < RS; o++) {
-                double t = (double)win[o + 8] * a.w[0];
+                using AccB = std::conditional_t<(OFLK_ABLATE & 8192) != 0, float, double>;   // (timing experiment: fp32)
+                AccB t = (AccB)win[o + 8] * (AccB)a.w[0];
 #pragma unroll
                 for (int k = 8; k >= 1; k--) {
-                    double sgm = (double)win[o + 8 - k] + (double)win[o + 8 + k];
-                    double m = sgm * a.w[k];
+                    AccB sgm = (AccB)win[o + 8 - k] + (AccB)win[o + 8 + k];
+                    AccB m = sgm * (AccB)a.w[k];
                     t = t + m;
                 }
                 int r = seg * RS + o;
@@ -1565,11 +1596,12 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
             for (int k = 0; k < CS + 16; k++) win[k] = s_v[row * kPVS + min(seg * CS + k, kPIW - 1)];
 #pragma unroll
             for (int o = 0; o < CS; o++) {
-                double t = (double)win[o + 8] * a.w[0];
+                using AccC = std::conditional_t<(OFLK_ABLATE & 16384) != 0, float, double>;   // (timing experiment: fp32)
+                AccC t = (AccC)win[o + 8] * (AccC)a.w[0];
 #pragma unroll
                 for (int k = 8; k >= 1; k--) {
-                    double sgm = (double)win[o + 8 - k] + (double)win[o + 8 + k];
-                    double m = sgm * a.w[k];
+                    AccC sgm = (AccC)win[o + 8 - k] + (AccC)win[o + 8 + k];
+                    AccC m = sgm * (AccC)a.w[k];
                     t = t + m;
                 }
                 if (seg * CS + o < kPBW) s_h[row * kPHS + seg * CS + o] = (float)t;
@@ -1585,6 +1617,10 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
         int o = tid + k * 256;
         int i = i0 + o / kPTW, j = j0 + o % kPTW;
         if (i >= a.Ho || j >= a.Wo) continue;
+        if constexpr ((OFLK_ABLATE & 32768) != 0) {   // timing experiment: no bilinear sampling
+            dst[(size_t)i * a.Wo + j] = s_h[(o / kPTW) * 2 * kPHS + (o % kPTW) * 2];
+            continue;
+        }
         double y = linspace_at(a.ly, i), x = linspace_at(a.lx, j);
         float r = 0.0f;
         if (!(y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1))) {
@@ -2023,6 +2059,203 @@ __global__ __launch_bounds__(256) void k_lk16(Lk16Args a)
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BASELINE config 5, streaming form: the same fp16 arithmetic contract as k_lk16 (gradients rounded to
+// fp16, the five products and every window sum in fp16, fp32 solve), with NO LDS and NO barrier.
+// A wave owns a strip of 64 image columns (lane = column) and walks down Hs rows of it:
+//   per row   one coalesced 256-byte load of each frame (requested PF rows ahead)
+//             avg (fp32), It; Sobel/8 of the row above from three avg rows held in registers, the
+//             x-neighbours through DPP wave shifts
+//             products {IxIx, IyIy}, {IxIy, IxIt}, {IyIt, 0} (packed fp16) into a ring of 2HW+1 rows held
+//             in registers (the loop is unrolled by the ring length: static slot indices)
+//             vertical sums = the ring's sum; horizontal sums = 2HW wave shifts of them
+//             fp32 solve and one coalesced store of u and v, HW + 1 rows behind the loads
+// Lanes R = HW + 1 .. 63 - R of a wave produce outputs (64 - 2R columns per strip); a segment of Hs rows
+// costs 2R extra rows of loads.  ~50 VGPRs: eight waves per SIMD, which is what hides the memory
+// latency here -- the tiled kernels sit at four or five.
+// ---------------------------------------------------------------------------
+struct Lk16sArgs {
+    const float *prev, *curr;   // [B][H][W]
+    float *u, *v;
+    int H, W, B;
+    int Hs, segs;               // rows per segment, segments per strip
+    float s_g, s_t;             // input scales (powers of two), see k_lk16
+    float det_thr;              // 1e-4 * s_g^4
+};
+
+template <int CTRL>
+__device__ __forceinline__ h2 wave_shift(h2 v)   // 0x138: lane i takes lane i-1's value; 0x130: lane i+1's
+{
+    return __builtin_bit_cast(h2, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float wave_shift(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <class F, int... J>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, J...>, F &&f)
+{
+    (f(std::integral_constant<int, J>{}), ...);
+}
+
+template <int HW>
+__global__ __launch_bounds__(256) void k_lk16s(Lk16sArgs a)
+{
+    constexpr int WPB = 4;   // waves per block: four neighbouring strips (1, 2, 8, 16 and a barrier per row were measured: no gain)
+    constexpr int R = HW + 1, S = 2 * HW + 1, OUTW = 64 - 2 * R, PF = OFLK_LK16_PF;
+    constexpr int SHR = 0x138, SHL = 0x130;   // DPP wave_shr:1 / wave_shl:1
+    const int lane = threadIdx.x & 63;
+    const int H = a.H, W = a.W;
+    const int strips = (W + OUTW - 1) / OUTW;
+    const int nwave = strips * a.segs * a.B;
+    const int nblk = (nwave + WPB - 1) / WPB;
+    // consecutive tasks (= neighbouring strips of one segment row) stay on one XCD: the 2R shared columns hit its L2
+    const int task = __builtin_amdgcn_readfirstlane(xcd_tile_index(blockIdx.x, nblk) * WPB + (int)(threadIdx.x >> 6));
+    if (task >= nwave) return;
+    const int b = task / (strips * a.segs);
+    const int t = task - b * (strips * a.segs);
+    const int seg = t / strips, strip = t - seg * strips;
+    const int x = strip * OUTW - R + lane;
+    const unsigned cxb = 4u * (unsigned)min(max(x, 0), W - 1);   // byte offset of the lane's (clamped) column in a row
+    const int ys = seg * a.Hs, ye = min(ys + a.Hs, H);
+    const size_t plane = (size_t)H * (size_t)W;
+    const float *__restrict__ prev = a.prev + (size_t)b * plane;
+    const float *__restrict__ curr = a.curr + (size_t)b * plane;
+    float *__restrict__ ou = a.u + (size_t)b * plane;
+    float *__restrict__ ov = a.v + (size_t)b * plane;
+    const float ha = 0.5f * a.s_g, st = a.s_t;
+    const bool lane_out = lane >= R && lane < 64 - R && x < W;
+    const bool col_interior = x >= HW && x < W - HW;
+
+    // a row's base pointer is wave-uniform (scalar registers); the lane adds a 32-bit byte offset
+    auto row_off = [&](int r) { return (size_t)min(max(r, 0), H - 1) * (size_t)W; };   // "symm" ring
+    // rows ys - R and ys - R + 1 prime the Sobel window; the loop starts at row r0 = ys - R + 2
+    const int r0 = ys - R + 2;
+    float a0, a1, it1;
+    {
+        const size_t o0 = row_off(r0 - 2), o1 = row_off(r0 - 1);
+        const float p0 = ld_off<float>(prev + o0, cxb), q0 = ld_off<float>(curr + o0, cxb);
+        const float p1 = ld_off<float>(prev + o1, cxb), q1 = ld_off<float>(curr + o1, cxb);
+        a0 = (p0 + q0) * ha;
+        a1 = (p1 + q1) * ha;
+        it1 = (p1 - q1) * st;
+    }
+    float pb[PF], qb[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        const size_t o = row_off(r0 + k);
+        pb[k] = ld_off<float>(prev + o, cxb);
+        qb[k] = ld_off<float>(curr + o, cxb);
+    }
+    // Vertical window sums over S rows with three packed adds per row and plane instead of S - 1: rows are taken in
+    // blocks of S (= one pass of the unrolled loop); ring[j] holds, for j above the current slot, the previous block's
+    // suffix sums G_j = c_j + .. + c_{S-1}, and below it the current block's rows; fw is the current block's prefix
+    // sum.  The window ending at slot j is G_{j+1} + fw.  (No subtraction anywhere: fp16 sums stay sums.)
+    // Blocks are aligned to ABSOLUTE gradient rows (slot = row mod S), so a pixel's sums are added in the same order
+    // wherever the segments are cut: the flow does not depend on Hs, on the batch size or on the frame's neighbours.
+    const h2 zero2 = h2{(_Float16)0.0f, (_Float16)0.0f};
+    h2 ring[S][3], fw[3] = {zero2, zero2, zero2};
+#pragma unroll
+    for (int j = 0; j < S; j++) ring[j][0] = ring[j][1] = ring[j][2] = zero2;
+
+    const int n_it = ye - ys + 2 * HW;   // rows r0 .. ye - 1 + R
+    const int j0 = ((r0 - 1) % S + S) % S;   // slot of the first gradient row (the first block of a segment is partial)
+    for (int i0 = -j0; i0 < n_it; i0 += S) {
+        static_for(std::make_integer_sequence<int, S>{}, [&](auto jc) {
+            constexpr int j = decltype(jc)::value;   // ring slot of this row: static, the ring stays in registers
+            const int i = i0 + j;
+            if (i < 0 || i >= n_it) return;   // uniform
+            const int r = r0 + i;
+            const float p = pb[0], q = qb[0];
+#pragma unroll
+            for (int k = 0; k + 1 < PF; k++) {
+                pb[k] = pb[k + 1];
+                qb[k] = qb[k + 1];
+            }
+            {
+                const size_t o = row_off(r + PF);   // rows past the segment's last are loaded and dropped (clamped: in bounds)
+                pb[PF - 1] = ld_off<float>(prev + o, cxb);
+                qb[PF - 1] = ld_off<float>(curr + o, cxb);
+            }
+            const float a2 = (p + q) * ha, itn = (p - q) * st;
+            // Sobel/8 of row r - 1 (lucas_kanade_core.py:32-40, flipped kernels: left minus right, top minus bottom)
+            const float sm = (a0 + a2) + 2.0f * a1, df = a0 - a2;
+            float ix, iy;
+            if constexpr ((OFLK_LK16_ABL & 16) != 0) {
+                ix = sm * 0.125f;
+                iy = df * 0.125f;
+            } else {
+                ix = (wave_shift<SHR>(sm) - wave_shift<SHL>(sm)) * 0.125f;
+                iy = ((wave_shift<SHR>(df) + wave_shift<SHL>(df)) + 2.0f * df) * 0.125f;
+            }
+            const _Float16 hx = (_Float16)ix, hy = (_Float16)iy, ht = (_Float16)it1;   // fp16 gradients
+            const h2 gxy = h2{hx, hy};
+            h2 c[3];
+            c[0] = gxy * gxy;                      // {IxIx, IyIy}
+            c[1] = h2{hx, hx} * h2{hy, ht};        // {IxIy, IxIt}
+            c[2] = h2{hy * ht, (_Float16)0.0f};    // {IyIt, -}
+            a0 = a1; a1 = a2; it1 = itn;
+            h2 vs[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                if constexpr ((OFLK_LK16_ABL & 8) != 0) {
+                    vs[pl] = c[pl];
+                    continue;
+                }
+                fw[pl] = j == 0 ? c[pl] : fw[pl] + c[pl];
+                vs[pl] = j == S - 1 ? fw[pl] : ring[(j + 1) % S][pl] + fw[pl];
+                ring[j][pl] = c[pl];
+            }
+            if constexpr (j == S - 1 && (OFLK_LK16_ABL & 8) == 0) {   // the block is complete: its rows become suffix sums for the next block
+#pragma unroll
+                for (int k = S - 2; k >= 1; k--)
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) ring[k][pl] = ring[k][pl] + ring[k + 1][pl];
+            }
+            const int o = r - R;   // the output row whose window is complete now
+            if (o >= ys) {         // uniform; o < ye by the loop bound
+                // horizontal: columns x - HW .. x + HW, the three registers interleaved (independent chains)
+                h2 l[3], rr[3], acc[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) l[pl] = rr[pl] = acc[pl] = vs[pl];
+#pragma unroll
+                for (int k = 0; k < ((OFLK_LK16_ABL & 1) ? 0 : HW); k++) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) {
+                        l[pl] = wave_shift<SHR>(l[pl]);
+                        rr[pl] = wave_shift<SHL>(rr[pl]);
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) acc[pl] = acc[pl] + (l[pl] + rr[pl]);
+                }
+                const float Sxx = (float)acc[0].x, Syy = (float)acc[0].y, Sxy = (float)acc[1].x, Sxt = (float)acc[1].y, Syt = (float)acc[2].x;
+                const float det = Sxx * Syy - Sxy * Sxy;
+                const float inv = __builtin_amdgcn_rcpf(det) * 2.0f;   // s_g / s_t = 2
+                const bool solve = fabsf(det) > a.det_thr && col_interior && o >= HW && o < H - HW;   // borders stay 0 (:101-108)
+                float uu = solve ? (Sxy * Syt - Syy * Sxt) * inv : 0.0f;
+                float vv = solve ? (Sxy * Sxt - Sxx * Syt) * inv : 0.0f;
+                if constexpr ((OFLK_LK16_ABL & 2) != 0) {
+                    uu = Sxx + Syy + Sxy;
+                    vv = Sxt + Syt;
+                }
+                if constexpr ((OFLK_LK16_ABL & 32) != 0) {   // timing experiment: 64-lane stores at 256-byte aligned addresses
+                    const size_t orow = (size_t)o * (size_t)W;
+                    const unsigned xa = (unsigned)min(strip * 64 + lane, W - 1);
+                    st_off<float>(ou + orow, 4u * xa, uu);
+                    st_off<float>(ov + orow, 4u * xa, vv);
+                } else
+                if (lane_out && ((OFLK_LK16_ABL & 4) == 0 || uu == 12345.678f)) {
+                    const size_t orow = (size_t)o * (size_t)W;   // uniform
+                    st_off<float>(ou + orow, 4u * (unsigned)x, uu);
+                    st_off<float>(ov + orow, 4u * (unsigned)x, vv);
+                }
+            }
+        });
     }
 }
 

@@ -141,6 +141,64 @@ def test_fp16_other_windows_and_ragged_shapes():
                 assert np.median(epe) <= 0.1, (H, W, win, float(np.median(epe)))
 
 
+def test_fp16_tiled_form_agrees_with_the_streaming_form(suite, monkeypatch):
+    """the library holds two kernels for this mode: the streaming one (default: one wave per 64-column strip,
+    everything in registers) and the LDS-tiled one (OFLK_LK16_TILED=1, kept for its tile sizing, DESIGN.md);
+    both meet the same tolerances and agree with each other to within fp16 rounding of the window sums"""
+    import lucas_kanade_core as K
+
+    p = suite["frame_0"].astype(np.float32)
+    for name in ("translate_medium", "rotate_medium", "zoom_in"):
+        c = suite[f"frame_1__{name}"].astype(np.float32)
+        for win in (5, 7):
+            monkeypatch.delenv("OFLK_LK16_TILED", raising=False)
+            su, sv = K.lucas_kanade_single_scale_fp16(p, c, win, 255.0)
+            monkeypatch.setenv("OFLK_LK16_TILED", "1")
+            tu, tv = K.lucas_kanade_single_scale_fp16(p, c, win, 255.0)
+            monkeypatch.delenv("OFLK_LK16_TILED")
+            u, v = K.lucas_kanade_single_scale(p, c, win)
+            for hu, hv in ((su, sv), (tu, tv)):
+                epe = np.sqrt((hu.astype(np.float64) - u) ** 2 + (hv.astype(np.float64) - v) ** 2)
+                assert np.median(epe) <= TOL_MEDIAN
+            d = np.sqrt((su.astype(np.float64) - tu) ** 2 + (sv.astype(np.float64) - tv) ** 2)
+            assert np.median(d) <= TOL_MEDIAN, (name, win, float(np.median(d)))
+
+
+def test_fp16_strip_and_segment_seams():
+    """the streaming kernel cuts the frame into 64 - 2R column strips and Hs-row segments: widths and heights
+    around those seams, several pairs per call, and a forced small segment height give the same flow as one
+    segment does (the arithmetic per pixel does not depend on the cut)"""
+    import os
+
+    import torch
+
+    import _oflk
+
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda", 0)
+    for (B, H, W, win) in ((2, 90, 56, 7), (1, 77, 113, 7), (3, 41, 58 * 3 + 1, 5), (1, 200, 129, 3)):
+        a = rng.integers(0, 256, (B, H, W)).astype(np.float32)
+        b = np.roll(a, (1, -1), (1, 2))
+        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        outs = []
+        for hs in (None, "8", "13"):
+            if hs is None:
+                os.environ.pop("OFLK_LK16_HS", None)
+            else:
+                os.environ["OFLK_LK16_HS"] = hs
+            u, v = torch.full_like(ta, 7.0), torch.full_like(ta, 7.0)
+            plan = _oflk.Plan(0, B, H, W, 1, win, 0)
+            plan.single_scale_fp16(ta.data_ptr(), tb.data_ptr(), u.data_ptr(), v.data_ptr(), 255.0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            plan.close()
+            outs.append((u.cpu().numpy(), v.cpu().numpy()))
+        os.environ.pop("OFLK_LK16_HS", None)
+        for u, v in outs[1:]:
+            assert np.array_equal(u, outs[0][0]) and np.array_equal(v, outs[0][1]), (B, H, W, win)
+        hw = win // 2
+        assert not outs[0][0][:, :hw].any() and not outs[0][0][:, -hw:].any() and not outs[0][0][:, :, :hw].any() and not outs[0][0][:, :, -hw:].any()
+
+
 def test_zz_write_report():
     out = ROOT / "gpurun_out"
     out.mkdir(exist_ok=True)
