@@ -46,6 +46,14 @@ if [ -f tools/liboflk_stamps.so ]; then
   OFLK_LIB=tools/liboflk_stamps.so timeout -k 10 200 python3 tools/stamps.py profiles/${TAG}_stamps_timeline.json > profiles/${TAG}_stamps_timeline.txt 2>&1 || true
   rm -f profiles/${TAG}_stamps_timeline.raw.npy
 fi
+# 6b. block lifetimes of the same launch, fp16 mode counters / memory-pattern ceilings / EPE report
+if [ -f tools/liboflk_bt.so ]; then
+  OFLK_LIB=tools/liboflk_bt.so timeout -k 10 200 python3 tools/block_times.py profiles/${TAG}_block_times.json > gpurun_out/bt_$TAG.log 2>&1 || true
+  rm -f profiles/${TAG}_block_times.raw.npy
+fi
+bash tools/pmc_fp16.sh $TAG > gpurun_out/pmc_fp16_$TAG.log 2>&1 && cp gpurun_out/pmc_fp16_$TAG/summary.txt profiles/${TAG}_pmc_fp16.txt || true
+[ -x tools/ubench/rowwalk ] && timeout -k 10 120 tools/ubench/rowwalk 76 > profiles/${TAG}_rowwalk.txt 2>&1 || true
+python3 -m pytest tests/test_gpu_fp16.py -q > gpurun_out/fp16_tests_$TAG.log 2>&1 && cp gpurun_out/fp16_epe.json profiles/${TAG}_fp16_epe.json || true
 # 7. every BASELINE config that fits one GPU, and BASELINE configs[3] as one job on this GPU
 python3 tools/measure_configs.py profiles/${TAG}_configs.json > gpurun_out/cfg_$TAG.log 2>&1 || tail -3 gpurun_out/cfg_$TAG.log
 python3 bench.py --config 4k64 --steps 5 --warmup 1 --no-one-pair > gpurun_out/bench_4k64_$TAG.log 2>&1 || tail -3 gpurun_out/bench_4k64_$TAG.log
