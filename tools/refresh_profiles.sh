@@ -52,6 +52,7 @@ if [ -f tools/liboflk_bt.so ]; then
   rm -f profiles/${TAG}_block_times.raw.npy
 fi
 bash tools/pmc_fp16.sh $TAG > gpurun_out/pmc_fp16_$TAG.log 2>&1 && cp gpurun_out/pmc_fp16_$TAG/summary.txt profiles/${TAG}_pmc_fp16.txt || true
+python3 tools/hbm_probe.py > profiles/${TAG}_hbm_probe.txt 2>&1 || true
 [ -x tools/ubench/rowwalk ] && timeout -k 10 120 tools/ubench/rowwalk 76 > profiles/${TAG}_rowwalk.txt 2>&1 || true
 python3 -m pytest tests/test_gpu_fp16.py -q > gpurun_out/fp16_tests_$TAG.log 2>&1 && cp gpurun_out/fp16_epe.json profiles/${TAG}_fp16_epe.json || true
 # 7. every BASELINE config that fits one GPU, and BASELINE configs[3] as one job on this GPU
