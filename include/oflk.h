@@ -253,6 +253,28 @@ int oflk_plan_metrics(oflk_plan *plan, const float *d_u, const float *d_v, const
 int oflk_flow_metrics(const float *u, const float *v, int B, int H, int W, const float *u_true,
                       const float *v_true, int y0, int y1, int x0, int x1, double *out);
 
+/* ---- RTL-bit-accurate integer mode ------------------ */
+/* What the reference's single-scale RTL computes for a frame pair streamed by
+ * rtl/common/frame_buffer_simple.sv -- rtl/common/line_buffer_5x5.sv:75-151 (window geometry),
+ * rtl/unopt/gradient_compute.sv:89-139 (averaged-frame Sobel >>> 3, It = prev - curr),
+ * rtl/unopt/window_accumulator.sv:100-189 (25 products per quantity, 32-bit sums),
+ * rtl/unopt/flow_solver.sv:82-149 (low-32-bit products, |det| > 1000, (num <<< 7) / det truncating,
+ * clamp to +-1024) -- i.e. the values `flow_u` / `flow_v` carry in S8.7 fixed point when the
+ * accumulator has ingested element k of the gradient stream.  It replaces an xsim run of
+ * tb/tb_optical_flow_top.sv as the golden model of the RTL; python/rtl_golden_model.py turns the
+ * per-element values into the testbench's sample sequence, summary and flow_field.txt.
+ *   prev, curr : uint8 [B][H][W], 5 <= H <= 512, 5 <= W <= 1024 (flow_y is 9, flow_x 10 bits wide)
+ *   u, v       : int16 [B][oflk_rtl_stream_length(H, W)] = [B][(H-4)(W-4)]
+ * The RTL's geometry is kept with its quirks (one-pixel stream offset, the accumulator's rows are
+ * not image rows, the window of a row's last position is mostly zero): oracle/rtl_model.py
+ * states it.  PARITY UNPINNED: the model is held equal to a cycle-by-cycle execution of the modules
+ * (oracle/rtl_cycle_sim.py), but no simulator output of the RTL as committed exists to pin either. */
+long oflk_rtl_stream_length(int H, int W);
+int oflk_rtl_flow_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W, short *u, short *v);
+/* device-resident form; enqueues one kernel on `stream` */
+int oflk_rtl_flow_u8_device(const unsigned char *d_prev, const unsigned char *d_curr, int B, int H, int W, short *d_u,
+                            short *d_v, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1460,6 +1460,60 @@ OFLK_API int oflk_single_scale_fp16(const float *prev, const float *curr, int B,
     return OFLK_OK;
 }
 
+// ---- RTL-bit-accurate integer mode ---------------------------------
+namespace {
+int check_rtl(const void *prev, const void *curr, int B, int H, int W, const void *u, const void *v)
+{
+    if (!prev || !curr || !u || !v) return fail(OFLK_ERR_INVALID, "NULL argument");
+    if (B < 1) return fail(OFLK_ERR_INVALID, "B must be >= 1");
+    if (H < 5 || W < 5) return fail(OFLK_ERR_INVALID, "the RTL's line buffers need H, W >= 5 (got %d x %d)", H, W);
+    if (W > kRtlMaxW || H > kRtlMaxH)
+        return fail(OFLK_ERR_UNSUPPORTED, "the RTL's coordinate ports are 10 / 9 bits wide: W <= %d, H <= %d (got %d x %d)", kRtlMaxW,
+                    kRtlMaxH, W, H);
+    return OFLK_OK;
+}
+}  // namespace
+
+OFLK_API long oflk_rtl_stream_length(int H, int W)
+{
+    return H < 5 || W < 5 ? 0 : (long)(H - 4) * (long)(W - 4);
+}
+
+OFLK_API int oflk_rtl_flow_u8_device(const unsigned char *d_prev, const unsigned char *d_curr, int B, int H, int W, short *d_u,
+                                     short *d_v, void *stream)
+{
+    int rc = check_rtl(d_prev, d_curr, B, H, W, d_u, d_v);
+    if (rc) return rc;
+    RtlArgs a{};
+    a.prev = d_prev; a.curr = d_curr; a.u = d_u; a.v = d_v;
+    a.H = H; a.W = W; a.B = B;
+    const long M = oflk_rtl_stream_length(H, W);
+    dim3 grid((unsigned)((M + kRtlChunk - 1) / kRtlChunk), (unsigned)B);
+    hipLaunchKernelGGL(k_rtl_flow, grid, dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_rtl_flow_u8(const unsigned char *prev, const unsigned char *curr, int B, int H, int W, short *u, short *v)
+{
+    int rc = check_rtl(prev, curr, B, H, W, u, v);
+    if (rc) return rc;
+    HostCtx *c = nullptr;
+    std::unique_lock<std::mutex> lk;
+    if ((rc = acquire(g_device.load(), &c, lk))) return rc;
+    const size_t n = (size_t)B * H * W, m = (size_t)B * (size_t)oflk_rtl_stream_length(H, W);
+    if ((rc = host_u8(*c, n))) return rc;
+    if ((rc = host_io(*c, (m + 1) / 2))) return rc;   // two int16 planes in the float32 scratch planes 2 and 3
+    short *d_u = reinterpret_cast<short *>(c->io[2]), *d_v = reinterpret_cast<short *>(c->io[3]);
+    HIP_TRY(hipMemcpyAsync(c->u8[0], prev, n, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(c->u8[1], curr, n, hipMemcpyHostToDevice, nullptr));
+    if ((rc = oflk_rtl_flow_u8_device(c->u8[0], c->u8[1], B, H, W, d_u, d_v, nullptr))) return rc;
+    HIP_TRY(hipMemcpyAsync(u, d_u, m * sizeof(short), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(v, d_v, m * sizeof(short), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OFLK_OK;
+}
+
 // ---- one process, several GPUs: the batch sharded over devices 0 .. n_gpus-1 ---------------
 OFLK_API int oflk_single_scale_batch_multi(const float *prev, const float *curr, int B, int H, int W,
                                            int window_size, int n_gpus, float *u, float *v)

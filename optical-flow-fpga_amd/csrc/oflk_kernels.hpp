@@ -2259,6 +2259,110 @@ __global__ __launch_bounds__(256) void k_lk16s(Lk16sArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// RTL-bit-accurate integer mode: what the reference's single-scale RTL computes
+// for a frame pair, per element k of its gradient stream -- rtl/common/line_buffer_5x5.sv:75-151 (window
+// geometry), rtl/unopt/gradient_compute.sv:89-139, window_accumulator.sv:100-189, flow_solver.sv:82-149 --
+// in S8.7 fixed point.  The geometry is the RTL's, quirks included (see oracle/rtl_model.py, which states it
+// and is held equal to a cycle-by-cycle execution of the modules): the gradient of stream position (r, c),
+// r, c >= 4, is taken on the 3x3 neighbourhood of pixels (r-2 .. r, c-4 .. c-2) and is zero for c = W-1; the
+// valid gradients form a stream of (H-4)(W-4) elements that the accumulator wraps at W, and element k's 5x5
+// window is  rows 0..3 x columns 0..3: k - (3-i) W - (4-j)  (zero when k mod W = W-1),
+//            rows 0..3, column 4:      k - (4-i) W,          row 4: k - (4-j).
+// A block takes 1024 consecutive elements of one pair: the 4 W + 1024 gradients they touch are computed
+// into LDS (12-bit values as int16), then every thread sums four windows and solves.  Integer work, a few
+// bytes per pixel: nothing here is shaped for the matrix cores.
+// PARITY UNPINNED: no output of the RTL as committed exists.
+// ---------------------------------------------------------------------------
+constexpr int kRtlChunk = 1024, kRtlMaxW = 1024, kRtlMaxH = 512;   // flow_x / flow_y are 10 / 9 bits wide (flow_solver.sv:34-37)
+
+struct RtlArgs {
+    const unsigned char *prev, *curr;   // [B][H][W]
+    short *u, *v;                       // [B][(H-4)(W-4)]  S8.7
+    int H, W, B;
+};
+
+__global__ __launch_bounds__(256) void k_rtl_flow(RtlArgs a)
+{
+    __shared__ short s_gx[4 * kRtlMaxW + kRtlChunk], s_gy[4 * kRtlMaxW + kRtlChunk], s_gt[4 * kRtlMaxW + kRtlChunk];
+    const int tid = threadIdx.x;
+    const int W = a.W, H = a.H, Wv = W - 4;
+    const int M = (H - 4) * Wv;
+    const int b = blockIdx.y;
+    const int k_lo = blockIdx.x * kRtlChunk, g_lo = k_lo - 4 * W, L = 4 * W + kRtlChunk;
+    const unsigned char *__restrict__ prev = a.prev + (size_t)b * H * W;
+    const unsigned char *__restrict__ curr = a.curr + (size_t)b * H * W;
+
+    // ---- gradients of stream elements g_lo .. g_lo + L - 1 (gradient_compute.sv:108-139) ----
+    for (int e = tid; e < L; e += 256) {
+        const int m = g_lo + e;
+        int gx = 0, gy = 0, gt = 0;
+        if (m >= 0 && m < M) {
+            const int r = m / Wv + 4, c = m - (m / Wv) * Wv + 4;   // stream position of the window
+            if (c != W - 1) {   // the window of a row's last position has only its newest column (line_buffer_5x5.sv:101-131)
+                int avg[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const int o = (r - 2 + i) * W + (c - 4 + j);   // pixel index: the stream runs one pixel behind the frame
+                        const int sc = (signed char)curr[o], sp = (signed char)prev[o];   // `logic signed [7:0]` ports
+                        avg[i][j] = ((sc + sp) & 0x1FF) >> 1;                             // 9-bit sum, logical shift
+                    }
+                const int xl = -avg[0][0] - (avg[1][0] << 1) - avg[2][0], xr = avg[0][2] + (avg[1][2] << 1) + avg[2][2];
+                const int yt = -avg[0][0] - (avg[0][1] << 1) - avg[0][2], yb = avg[2][0] + (avg[2][1] << 1) + avg[2][2];
+                gx = (xl + xr) >> 3;   // arithmetic: >>> of a signed sum
+                gy = (yt + yb) >> 3;
+                const int oc = (r - 1) * W + (c - 3);
+                gt = (int)prev[oc] - (int)curr[oc];   // zero-extended pixels (:139)
+            }
+        }
+        s_gx[e] = (short)gx;
+        s_gy[e] = (short)gy;
+        s_gt[e] = (short)gt;
+    }
+    __syncthreads();
+
+    // ---- window sums and solve ----
+#pragma unroll 1
+    for (int q = 0; q < kRtlChunk / 256; q++) {
+        const int k = k_lo + tid + 256 * q;
+        if (k >= M) break;
+        const int c2 = k % W;
+        const bool edge = c2 == W - 1;
+        const int base = k - g_lo;   // LDS index of element k
+        int sxx = 0, syy = 0, sxy = 0, sxt = 0, syt = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int off = i == 4 ? 4 - j : (j == 4 ? (4 - i) * W : (3 - i) * W + (4 - j));
+                const bool zero = edge && i < 4 && j < 4;
+                const int e = base - off;   // >= 0: base >= 4 W
+                const int x = zero ? 0 : s_gx[e], y = zero ? 0 : s_gy[e], t = zero ? 0 : s_gt[e];
+                sxx += x * x;   // 25 products of 12-bit values: 32 bits never overflow (window_accumulator.sv:128-166)
+                syy += y * y;
+                sxy += x * y;
+                sxt += x * t;
+                syt += y * t;
+            }
+        // flow_solver.sv:82-149: products keep their low 32 bits
+        auto lo = [](int p, int r) { return (int)((unsigned)p * (unsigned)r); };
+        const int det = (int)((unsigned)lo(sxx, syy) - (unsigned)lo(sxy, sxy));
+        const int nu = (int)((unsigned)lo(syy, sxt) - (unsigned)lo(sxy, syt));
+        const int nv = (int)((unsigned)lo(sxx, syt) - (unsigned)lo(sxy, sxt));
+        int fu = 0, fv = 0;
+        if (det > 1000 || det < -1000) {
+            fu = (short)(((long long)nu * 128) / det);   // 39-bit quotient truncated towards zero, low 16 bits kept
+            fv = (short)(((long long)nv * 128) / det);
+            fu = fu > 1024 ? 1024 : (fu < -1024 ? -1024 : fu);
+            fv = fv > 1024 ? 1024 : (fv < -1024 ? -1024 : fv);
+        }
+        a.u[(size_t)b * M + k] = (short)fu;
+        a.v[(size_t)b * M + k] = (short)fv;
+    }
+}
+
 // a1 standalone: compute_gradients (lucas_kanade_core.py:15-45)
 __global__ __launch_bounds__(256) void k_gradients(const float *__restrict__ prev,
                                                    const float *__restrict__ curr,

@@ -59,6 +59,9 @@ SIGNATURES = {
     "oflk_pyramidal_u8_multi": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
     "oflk_shard_range": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p]),
     "oflk_single_scale_fp16": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _f32p, _f32p]),
+    "oflk_rtl_stream_length": (ctypes.c_long, [ctypes.c_int, ctypes.c_int]),
+    "oflk_rtl_flow_u8": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "oflk_rtl_flow_u8_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "oflk_plan_single_scale_fp16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp]),
     "oflk_plan_resolve_uncertain": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
     "oflk_plan_resolve_uncertain_u8": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32p]),

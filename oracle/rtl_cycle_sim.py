@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
-"""Experiment: literal, cycle-by-cycle execution of the reference's single-scale RTL pipeline
-(rtl/common/frame_buffer_simple.sv, line_buffer_5x5.sv; rtl/unopt/gradient_compute.sv,
-window_accumulator.sv, flow_solver.sv, optical_flow_top.sv) and of the monitor loop of
-tb/tb_optical_flow_top.sv, to see whether the numbers of the xsim log in README.md:455-531 come
-out (73 289 valid vectors, first vector at (10, 8), region mean u = -0.765, v = -0.053, ...).
-Registers update with non-blocking semantics: every process computes its next state from the
-current state, then all commit together."""
+"""TEST INFRASTRUCTURE (oracle of the RTL-bit-accurate integer mode) -- never on
+the product path: only tests/ may import this.
+
+Literal, cycle-by-cycle execution of the reference's single-scale RTL pipeline
+(rtl/common/frame_buffer_simple.sv, rtl/common/line_buffer_5x5.sv:48-151; rtl/unopt/gradient_compute.sv:89-159,
+window_accumulator.sv:100-189, flow_solver.sv:52-166, optical_flow_top.sv) and of the monitor loop of
+tb/tb_optical_flow_top.sv:176-240: what the testbench would sample from `flow_valid / flow_x / flow_y /
+flow_u / flow_v`, vector by vector.  Registers update with non-blocking semantics: every process computes
+its next state from the current state, then all commit together.
+
+PARITY UNPINNED: Vivado / xsim is not available here and the reference holds no output of the RTL as
+committed.  The only golden data, the xsim log in README.md:455-531, was produced by an earlier revision of
+the solver and testbench: this simulation reproduces its vector count to within two (73 287 against 73 289)
+and its zero samples but not its values (first vector at (3, 2) against (10, 8); region mean u = 0.73
+against -0.765).  A later round with a simulator, or a maintainer's fresh log, can pin it.
+
+Usage: python3 oracle/rtl_cycle_sim.py [sinusoid|natural]   (the tb's summary for tests/golden/rtl_frames.npz)
+"""
 import sys
 from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parents[2]
-W, H = 320, 240
-TOTAL = W * H
+ROOT = Path(__file__).resolve().parents[1]
 
 
 def s8(x):
@@ -29,7 +38,8 @@ def sx(x, bits):
 class LineBuf:
     """line_buffer_5x5.sv"""
 
-    def __init__(self):
+    def __init__(self, W, H):
+        self.W, self.H = W, H
         self.l0 = [0] * W
         self.l1 = [0] * W
         self.l2 = [0] * W
@@ -59,9 +69,9 @@ class LineBuf:
             return lambda: None
         c, r = self.col, self.row
         ncur = [data_in] + self.cur[:4]
-        if c == W - 1:
+        if c == self.W - 1:
             ncol = 0
-            nrow = 0 if r == H - 1 else r + 1
+            nrow = 0 if r == self.H - 1 else r + 1
         else:
             ncol, nrow = c + 1, r
         nvalid = 1 if (r >= 4 and c >= 4) else 0
@@ -79,12 +89,15 @@ def trunc_div(a, b):
     return q if (a >= 0) == (b >= 0) else -q
 
 
-def simulate(f0, f1, verbose=True):
+def simulate(f0, f1, W=320, H=240):
+    """f0 = previous frame, f1 = current frame, flat uint8 sequences of W * H pixels; returns the list of
+    (flow_x, flow_y, flow_u, flow_v) the testbench's monitor loop samples, in order (u, v: S8.7 integers)"""
+    TOTAL = W * H
     # ---- state ------------------------------------------------------------------
     fb = dict(cnt=0, streaming=0, valid=0, done=0, curr=0, prev=0)
-    lb_c, lb_p = LineBuf(), LineBuf()
+    lb_c, lb_p = LineBuf(W, H), LineBuf(W, H)
     g = dict(gx=0, gy=0, gt=0, valid=0)
-    lb_x, lb_y, lb_t = LineBuf(), LineBuf(), LineBuf()
+    lb_x, lb_y, lb_t = LineBuf(W, H), LineBuf(W, H), LineBuf(W, H)
     acc = dict(prod=None, valid_d1=0, x_d1=0, y_d1=0, sums=[0] * 5, valid=0, x=0, y=0)
     acc["prod"] = [[0] * 25 for _ in range(5)]
     sol = dict(p=[0] * 6, valid_d1=0, x_d1=0, y_d1=0, u=0, v=0, valid=0, x=0, y=0)
@@ -223,61 +236,11 @@ def report(outputs):
 def main():
     z = np.load(ROOT / "tests/golden/rtl_frames.npz")
     which = sys.argv[1] if len(sys.argv) > 1 else "sinusoid"
-    f0 = z[f"{which}__frame_00"].astype(np.int64).reshape(-1)
-    f1 = z[f"{which}__frame_01"].astype(np.int64).reshape(-1)
-    report(simulate(f0, f1))
+    f0 = z[f"{which}__frame_00"].astype(np.int64)
+    f1 = z[f"{which}__frame_01"].astype(np.int64)
+    H, W = f0.shape
+    report(simulate(f0.reshape(-1), f1.reshape(-1), W, H))
 
 
-if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] not in ("debug", "counter")):
+if __name__ == "__main__":
     main()
-
-
-def debug():
-    z = np.load(ROOT / "tests/golden/rtl_frames.npz")
-    f0 = z["sinusoid__frame_00"].astype(np.int64).reshape(-1)
-    f1 = z["sinusoid__frame_01"].astype(np.int64).reshape(-1)
-    out = simulate(f0, f1)
-    print(out[:12])
-    import collections
-    c = collections.Counter((x, y) for x, y, _, _ in out)
-    print("most repeated coords:", c.most_common(5))
-    print("distinct coords:", len(c))
-    rows = collections.Counter(y for _, y, _, _ in out)
-    print("rows present:", min(rows), max(rows), "outputs in row 100:", rows[100], "row 0:", rows[0])
-    idx = [i for i, o in enumerate(out) if o[:2] == (10, 8)]
-    print("index of (10,8):", idx[:3])
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "debug":
-    debug()
-
-
-def counter_hypothesis(offsets=(2570,)):
-    """README log hypothesis: the log was made by an older testbench that derived each vector's
-    position from a running pixel counter (first vector at raster index 2570 = (10, 8)) instead of
-    the RTL's flow_x / flow_y."""
-    z = np.load(ROOT / "tests/golden/rtl_frames.npz")
-    f0 = z["sinusoid__frame_00"].astype(np.int64).reshape(-1)
-    f1 = z["sinusoid__frame_01"].astype(np.int64).reshape(-1)
-    out = simulate(f0, f1)
-    for off in offsets:
-        n = 0
-        su = sv = squ = sqv = 0.0
-        samples = []
-        for k, (_, _, u, v) in enumerate(out):
-            pos = off + k
-            x, y = pos % W, pos // W
-            if 55 <= x <= 85 and 105 <= y <= 135:
-                uf, vf = u / 128.0, v / 128.0
-                su += uf; sv += vf; squ += uf * uf; sqv += vf * vf
-                n += 1
-                if n % 100 == 1:
-                    samples.append((x, y, uf, vf))
-        mu, mv = su / n, sv / n
-        print(f"offset {off}: n={n} mean u={mu:6.3f} v={mv:6.3f} std u={(squ/n-mu*mu)**0.5:6.3f} v={(sqv/n-mv*mv)**0.5:6.3f}")
-        for smp in samples[:10]:
-            print("  [x=%3d, y=%3d] u=%6.3f, v=%6.3f" % smp)
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "counter":
-    counter_hypothesis()

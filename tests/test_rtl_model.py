@@ -1,0 +1,62 @@
+"""Oracle of the RTL-bit-accurate integer mode, CPU only.
+
+PARITY UNPINNED: there is no simulator in this image and the reference holds no output of the RTL as
+committed (the xsim log in its README is from an earlier revision: oracle/rtl_cycle_sim.py's header).  What
+these tests hold: the data-parallel closed form (oracle/rtl_model.py), which is what the GPU kernel is
+compared with, equals the literal cycle-by-cycle execution of the RTL modules and of the testbench's monitor
+loop (oracle/rtl_cycle_sim.py) vector for vector.
+"""
+import numpy as np
+import pytest
+
+
+def _pairs(rng, H, W):
+    yy, xx = np.mgrid[0:H, 0:W]
+    tex = (128 + 100 * np.sin(xx / 3.0) * np.cos(yy / 4.0)).astype(np.int64)
+    flat = rng.integers(100, 140, (H, W))
+    return [(rng.integers(0, 256, (H, W)), rng.integers(0, 256, (H, W))),      # every code path of the signed-pixel average
+            (flat, np.roll(flat, 1, 1)),                                         # small determinants
+            (tex, np.roll(tex, (1, 2), (0, 1)))]                                 # textured motion, clamped flows
+
+
+@pytest.mark.parametrize("shape", [(12, 16), (24, 40), (31, 17), (17, 33), (12, 11), (9, 30), (10, 9), (5, 5), (6, 64)])
+def test_closed_form_equals_the_cycle_simulation(shape):
+    import rtl_cycle_sim as S
+    import rtl_model as M
+
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    for f0, f1 in _pairs(rng, H, W):
+        f0, f1 = f0.astype(np.uint8), f1.astype(np.uint8)
+        sim = np.array(S.simulate(f0.reshape(-1).astype(np.int64), f1.reshape(-1).astype(np.int64), W, H), np.int64).reshape(-1, 4)
+        mod = M.testbench_vectors(f0, f1)
+        assert mod.shape == sim.shape and np.array_equal(mod, sim), shape
+
+
+def test_closed_form_equals_the_cycle_simulation_on_the_rtl_frames(golden_dir):
+    """the frame pair the reference's testbench loads (tb/test_frames, 320x240): 73 287 sampled vectors, the
+    first at (3, 2); the xsim log of README.md:455-531 (an earlier RTL revision) says 73 289 and (10, 8)"""
+    import rtl_cycle_sim as S
+    import rtl_model as M
+
+    z = np.load(golden_dir / "rtl_frames.npz")
+    f0, f1 = z["sinusoid__frame_00"], z["sinusoid__frame_01"]
+    sim = np.array(S.simulate(f0.reshape(-1).astype(np.int64), f1.reshape(-1).astype(np.int64), 320, 240), np.int64)
+    mod = M.testbench_vectors(f0, f1)
+    assert len(sim) == 73287 and tuple(sim[0, :2]) == (3, 2)
+    assert np.array_equal(mod, sim)
+    assert int((np.abs(sim[:, 2:]) == 1024).sum()) > 0 and int((sim[:, 2] != 0).sum()) > 40000   # clamp and solve both exercised
+
+
+def test_window_geometry_of_the_line_buffer():
+    """line_buffer_5x5.sv:75-151 as the model states it: the newest complete row appears twice, the last
+    column comes from one row further up, and a row's last position keeps only that column"""
+    import rtl_model as M
+
+    W = 20
+    k = np.array([7 * W + 9, 7 * W + W - 1])
+    idx = M.window_indices(k, W).reshape(2, 5, 5)
+    assert idx[0, 4].tolist() == [k[0] - 4, k[0] - 3, k[0] - 2, k[0] - 1, k[0]]
+    assert idx[0, 3, :4].tolist() == idx[0, 4, :4].tolist()                      # row 3 repeats the current row
+    assert idx[0, :4, 4].tolist() == [k[0] - 4 * W, k[0] - 3 * W, k[0] - 2 * W, k[0] - W]
+    assert (idx[1, :4, :4] == -1).all() and idx[1, :4, 4].tolist() == [k[1] - 4 * W, k[1] - 3 * W, k[1] - 2 * W, k[1] - W]

@@ -68,6 +68,28 @@ def main():
     run("configs[4]: 7680x4320 pair, 7x7 window, fp16 gradients/accumulators (single-scale)", 1, 4320, 7680, 1, 7, 0, 20, "fp16")
     run("configs[4] geometry, exact fp32 arithmetic for comparison", 1, 4320, 7680, 1, 7, 0, 20)
     run("configs[4] geometry, 3-level pyramidal 7x7 x3, exact fp32", 1, 4320, 7680, 3, 7, 3, 10)
+    # the RTL-bit-accurate integer mode, the RTL's own frame size
+    for B, H, W, reps in ((1, 240, 320, 200), (256, 240, 320, 20), (64, 512, 1024, 20)):
+        p8 = torch.randint(0, 256, (B, H, W), dtype=torch.uint8, device=dev)
+        c8 = torch.randint(0, 256, (B, H, W), dtype=torch.uint8, device=dev)
+        M = (H - 4) * (W - 4)
+        du = torch.empty((B, M), dtype=torch.int16, device=dev)
+        dv = torch.empty_like(du)
+        fn = lambda: _oflk.check(_oflk.lib().oflk_rtl_flow_u8_device(p8.data_ptr(), c8.data_ptr(), B, H, W, du.data_ptr(), dv.data_ptr(), stream))  # noqa: E731
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        n = B * H * W
+        row = {"config": f"RTL-bit-accurate integer mode (f3), {W}x{H} uint8 frames", "mode": "rtl_int", "pairs": B, "shape": [H, W],
+               "us_per_call": round(dt * 1e6, 1), "Mpix_per_s": round(n / dt / 1e6, 1), "algorithmic_GBs": round(n * 6.0 / dt / 1e9, 1),
+               "frac_of_8TBs": round(n * 6.0 / dt / 8e12, 4), "note": "2 B/px in (two uint8 frames), 4 B/px out (two int16 planes)"}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
     Path(out_path).write_text(json.dumps({"device": torch.cuda.get_device_name(0), "inputs": "resident in HBM, synthetic",
                                           "rows": rows}, indent=1))
 
