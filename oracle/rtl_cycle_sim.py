@@ -13,7 +13,9 @@ PARITY UNPINNED: Vivado / xsim is not available here and the reference holds no 
 committed.  The only golden data, the xsim log in README.md:455-531, was produced by an earlier revision of
 the solver and testbench: this simulation reproduces its vector count to within two (73 287 against 73 289)
 and its zero samples but not its values (first vector at (3, 2) against (10, 8); region mean u = 0.73
-against -0.765).  A later round with a simulator, or a maintainer's fresh log, can pin it.
+against -0.765).  The reference's other artefact, results/flow_visualization.png (statistics of a run on the
+mountain frames: 73 289 vectors, 856 in the test region, mean u = 1.459), is matched in geometry (856) and to 5 % in
+value (1.388): tests/test_rtl_model.py.  A later round with a simulator, or a maintainer's fresh log, can pin it.
 
 Usage: python3 oracle/rtl_cycle_sim.py [sinusoid|natural]   (the tb's summary for tests/golden/rtl_frames.npz)
 """
