@@ -1489,7 +1489,8 @@ OFLK_API int oflk_rtl_flow_u8_device(const unsigned char *d_prev, const unsigned
     a.H = H; a.W = W; a.B = B;
     const long M = oflk_rtl_stream_length(H, W);
     dim3 grid((unsigned)((M + kRtlChunk - 1) / kRtlChunk), (unsigned)B);
-    hipLaunchKernelGGL(k_rtl_flow, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const size_t lds = (size_t)(4 * W + kRtlChunk) * sizeof(short4);   // <= 48 KB at W = 1024
+    hipLaunchKernelGGL(k_rtl_flow, grid, dim3(256), lds, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return OFLK_OK;
 }

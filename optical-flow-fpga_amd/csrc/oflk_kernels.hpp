@@ -2269,12 +2269,13 @@ __global__ __launch_bounds__(256) void k_lk16s(Lk16sArgs a)
 // valid gradients form a stream of (H-4)(W-4) elements that the accumulator wraps at W, and element k's 5x5
 // window is  rows 0..3 x columns 0..3: k - (3-i) W - (4-j)  (zero when k mod W = W-1),
 //            rows 0..3, column 4:      k - (4-i) W,          row 4: k - (4-j).
-// A block takes 1024 consecutive elements of one pair: the 4 W + 1024 gradients they touch are computed
-// into LDS (12-bit values as int16), then every thread sums four windows and solves.  Integer work, a few
+// A block takes 2048 consecutive elements of one pair: the 4 W + 2048 gradients they touch are computed
+// into LDS ({gx, gy, gt} as one 8-byte cell), then every thread sums the windows of two groups of four adjacent
+// elements (52 cells read for 4 x 25) and solves.  Integer work, a few
 // bytes per pixel: nothing here is shaped for the matrix cores.
 // PARITY UNPINNED: no output of the RTL as committed exists.
 // ---------------------------------------------------------------------------
-constexpr int kRtlChunk = 1024, kRtlMaxW = 1024, kRtlMaxH = 512;   // flow_x / flow_y are 10 / 9 bits wide (flow_solver.sv:34-37)
+constexpr int kRtlChunk = 2048, kRtlMaxW = 1024, kRtlMaxH = 512;   // flow_x / flow_y are 10 / 9 bits wide (flow_solver.sv:34-37)
 
 struct RtlArgs {
     const unsigned char *prev, *curr;   // [B][H][W]
@@ -2282,9 +2283,32 @@ struct RtlArgs {
     int H, W, B;
 };
 
+// floor(|a| / |b|) with the sign of a / b: Verilog's signed `/` truncates towards zero (flow_solver.sv:121-122).
+// |a| < 2^39, 1000 < |b| < 2^31.  `rb` ~ 1 / |b| to fp64 accuracy (shared by the two quotients of an element): the
+// product is within one of the integer quotient, the remainder settles it.
+__device__ __forceinline__ double rtl_recip(int b)
+{
+    const double d = (double)(b < 0 ? -(long long)b : (long long)b);
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ long long rtl_trunc_div(long long a, int b, double rb)
+{
+    const unsigned long long ua = (unsigned long long)(a < 0 ? -a : a);
+    const unsigned long long ub = (unsigned long long)(b < 0 ? -(long long)b : (long long)b);
+    unsigned long long q = (unsigned long long)((double)ua * rb);
+    const long long r = (long long)ua - (long long)(q * ub);
+    if (r < 0) q -= 1;
+    else if ((unsigned long long)r >= ub) q += 1;
+    return ((a < 0) != (b < 0)) ? -(long long)q : (long long)q;
+}
+
 __global__ __launch_bounds__(256) void k_rtl_flow(RtlArgs a)
 {
-    __shared__ short s_gx[4 * kRtlMaxW + kRtlChunk], s_gy[4 * kRtlMaxW + kRtlChunk], s_gt[4 * kRtlMaxW + kRtlChunk];
+    // gradients of stream elements g_lo .. g_lo + L - 1 as {gx, gy, gt, 0}: one 8-byte LDS read per window element
+    extern __shared__ __attribute__((aligned(16))) short4 s_g[];
     const int tid = threadIdx.x;
     const int W = a.W, H = a.H, Wv = W - 4;
     const int M = (H - 4) * Wv;
@@ -2293,73 +2317,144 @@ __global__ __launch_bounds__(256) void k_rtl_flow(RtlArgs a)
     const unsigned char *__restrict__ prev = a.prev + (size_t)b * H * W;
     const unsigned char *__restrict__ curr = a.curr + (size_t)b * H * W;
 
-    // ---- gradients of stream elements g_lo .. g_lo + L - 1 (gradient_compute.sv:108-139) ----
-    for (int e = tid; e < L; e += 256) {
-        const int m = g_lo + e;
-        int gx = 0, gy = 0, gt = 0;
-        if (m >= 0 && m < M) {
-            const int r = m / Wv + 4, c = m - (m / Wv) * Wv + 4;   // stream position of the window
-            if (c != W - 1) {   // the window of a row's last position has only its newest column (line_buffer_5x5.sv:101-131)
-                int avg[3][3];
+    // ---- gradients (gradient_compute.sv:108-139): a thread takes four adjacent stream elements; when they lie in one
+    // image row (all but the groups that straddle a row end) their 3 x 6 pixels come as one 8-byte load per row and
+    // frame instead of 18 byte loads per element ----
+    auto gradient = [&](auto px) {   // px(frame, i, j): pixel of the element's 3x3 neighbourhood, frame 0 = curr, 1 = prev
+        int avg[3][3];
 #pragma unroll
-                for (int i = 0; i < 3; i++)
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        const int o = (r - 2 + i) * W + (c - 4 + j);   // pixel index: the stream runs one pixel behind the frame
-                        const int sc = (signed char)curr[o], sp = (signed char)prev[o];   // `logic signed [7:0]` ports
-                        avg[i][j] = ((sc + sp) & 0x1FF) >> 1;                             // 9-bit sum, logical shift
-                    }
-                const int xl = -avg[0][0] - (avg[1][0] << 1) - avg[2][0], xr = avg[0][2] + (avg[1][2] << 1) + avg[2][2];
-                const int yt = -avg[0][0] - (avg[0][1] << 1) - avg[0][2], yb = avg[2][0] + (avg[2][1] << 1) + avg[2][2];
-                gx = (xl + xr) >> 3;   // arithmetic: >>> of a signed sum
-                gy = (yt + yb) >> 3;
-                const int oc = (r - 1) * W + (c - 3);
-                gt = (int)prev[oc] - (int)curr[oc];   // zero-extended pixels (:139)
+            for (int j = 0; j < 3; j++) {
+                const int sc = (signed char)px(0, i, j), sp = (signed char)px(1, i, j);   // `logic signed [7:0]` ports
+                avg[i][j] = ((sc + sp) & 0x1FF) >> 1;                                     // 9-bit sum, logical shift
+            }
+        const int xl = -avg[0][0] - (avg[1][0] << 1) - avg[2][0], xr = avg[0][2] + (avg[1][2] << 1) + avg[2][2];
+        const int yt = -avg[0][0] - (avg[0][1] << 1) - avg[0][2], yb = avg[2][0] + (avg[2][1] << 1) + avg[2][2];
+        const int gt = (int)px(1, 1, 1) - (int)px(0, 1, 1);   // zero-extended pixels (:139)
+        return make_short4((short)((xl + xr) >> 3), (short)((yt + yb) >> 3), (short)gt, 0);   // >>> of a signed sum
+    };
+    const int m_a = g_lo > 0 ? g_lo : 0, m_b = (g_lo + L < M ? g_lo + L : M) - 1;   // stream elements of this block that exist
+    for (int e = tid; e < L; e += 256)   // cells before the stream's start / past its end read as zero
+        if (g_lo + e < 0 || g_lo + e >= M) s_g[e] = make_short4(0, 0, 0, 0);
+    if (W >= 8) {
+        // groups of four elements of one image row (the row's last group may be shorter): every group takes the 8-byte path
+        const int gpr = (Wv + 3) >> 2, row_a = m_a / Wv, nrow = m_b / Wv - row_a + 1;
+#pragma unroll 1
+        for (int t = tid; t < nrow * gpr; t += 256) {
+            const int rw = row_a + t / gpr, cg = t - (t / gpr) * gpr;
+            const int r = rw + 4, c = 4 * cg + 4;            // stream position of the group's first window
+            const int start = min(c - 4, W - 8), sh = 8 * (c - 4 - start);   // the row's last group reads from W-8 and shifts
+            unsigned long long w[2][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                __builtin_memcpy(&w[0][i], curr + (r - 2 + i) * W + start, 8);   // pixels (r-2 .. r, c-4 ..): the stream runs one
+                __builtin_memcpy(&w[1][i], prev + (r - 2 + i) * W + start, 8);   // pixel behind the frame
+                w[0][i] >>= sh;
+                w[1][i] >>= sh;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int cc = c + q, m = rw * Wv + 4 * cg + q;
+                if (cc < W && m >= m_a && m <= m_b) {
+                    const short4 g = gradient([&](int f, int i, int j) { return (unsigned char)(w[f][i] >> (8 * (q + j))); });
+                    // the window of a row's last position has only its newest column (line_buffer_5x5.sv:101-131)
+                    s_g[m - g_lo] = cc == W - 1 ? make_short4(0, 0, 0, 0) : g;
+                }
             }
         }
-        s_gx[e] = (short)gx;
-        s_gy[e] = (short)gy;
-        s_gt[e] = (short)gt;
+    } else {
+#pragma unroll 1
+        for (int e = tid; e < L; e += 256) {
+            const int m = g_lo + e;
+            if (m < 0 || m >= M) continue;
+            const int rr = m / Wv + 4, cc = m % Wv + 4;
+            s_g[e] = cc == W - 1 ? make_short4(0, 0, 0, 0)
+                                 : gradient([&](int f, int i, int j) { return (f ? prev : curr)[(rr - 2 + i) * W + (cc - 4 + j)]; });
+        }
     }
     __syncthreads();
 
-    // ---- window sums and solve ----
+    // ---- window sums and solve: a thread takes groups of four ADJACENT elements, whose windows share most cells ----
 #pragma unroll 1
-    for (int q = 0; q < kRtlChunk / 256; q++) {
-        const int k = k_lo + tid + 256 * q;
-        if (k >= M) break;
-        const int c2 = k % W;
-        const bool edge = c2 == W - 1;
-        const int base = k - g_lo;   // LDS index of element k
-        int sxx = 0, syy = 0, sxy = 0, sxt = 0, syt = 0;
+    for (int q = 0; q < kRtlChunk / 1024; q++) {
+        const int kb = k_lo + 1024 * q + 4 * tid;   // first element of the group
+        if (kb >= M) break;
+        const int base = kb - g_lo;                 // LDS index of element kb (>= 4 W)
+        // five sums per element: first the 4 x 4 block of rows 0..3 / columns 0..3, which is zero as a whole when
+        // the element is a row's last position, then column 4 and row 4 on top of it
+        int sm[4][5];
 #pragma unroll
-        for (int i = 0; i < 5; i++)
+        for (int o = 0; o < 4; o++)
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int off = i == 4 ? 4 - j : (j == 4 ? (4 - i) * W : (3 - i) * W + (4 - j));
-                const bool zero = edge && i < 4 && j < 4;
-                const int e = base - off;   // >= 0: base >= 4 W
-                const int x = zero ? 0 : s_gx[e], y = zero ? 0 : s_gy[e], t = zero ? 0 : s_gt[e];
-                sxx += x * x;   // 25 products of 12-bit values: 32 bits never overflow (window_accumulator.sv:128-166)
-                syy += y * y;
-                sxy += x * y;
-                sxt += x * t;
-                syt += y * t;
-            }
-        // flow_solver.sv:82-149: products keep their low 32 bits
-        auto lo = [](int p, int r) { return (int)((unsigned)p * (unsigned)r); };
-        const int det = (int)((unsigned)lo(sxx, syy) - (unsigned)lo(sxy, sxy));
-        const int nu = (int)((unsigned)lo(syy, sxt) - (unsigned)lo(sxy, syt));
-        const int nv = (int)((unsigned)lo(sxx, syt) - (unsigned)lo(sxy, sxt));
-        int fu = 0, fv = 0;
-        if (det > 1000 || det < -1000) {
-            fu = (short)(((long long)nu * 128) / det);   // 39-bit quotient truncated towards zero, low 16 bits kept
-            fv = (short)(((long long)nv * 128) / det);
-            fu = fu > 1024 ? 1024 : (fu < -1024 ? -1024 : fu);
-            fv = fv > 1024 ? 1024 : (fv < -1024 ? -1024 : fv);
+            for (int p = 0; p < 5; p++) sm[o][p] = 0;
+        auto add = [](int (&acc)[5], short4 g) {
+            const int x = g.x, y = g.y, t = g.z;
+            acc[0] += x * x;   // 25 products of 12-bit values: 32 bits never overflow (window_accumulator.sv:128-166)
+            acc[1] += y * y;
+            acc[2] += x * y;
+            acc[3] += x * t;
+            acc[4] += y * t;
+        };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // index kb + o - (3-i) W - (4-j): seven cells serve the four elements
+            short4 row[7];
+#pragma unroll
+            for (int c = 0; c < 7; c++) row[c] = s_g[base - (3 - i) * W - 4 + c];
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) add(sm[o], row[o + j]);
+            __builtin_amdgcn_sched_barrier(0);   // one window row's cells in registers at a time
         }
-        a.u[(size_t)b * M + k] = (short)fu;
-        a.v[(size_t)b * M + k] = (short)fv;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const bool edge = (kb + o) % W == W - 1;
+#pragma unroll
+            for (int p = 0; p < 5; p++) sm[o][p] = edge ? 0 : sm[o][p];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)   // column 4: index kb + o - (4-i) W
+#pragma unroll
+            for (int o = 0; o < 4; o++) add(sm[o], s_g[base + o - (4 - i) * W]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            short4 row[8];   // row 4: kb + o - (4-j)
+#pragma unroll
+            for (int c = 0; c < 8; c++) row[c] = s_g[base - 4 + c];
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int j = 0; j < 5; j++) add(sm[o], row[o + j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int sxx[4], syy[4], sxy[4], sxt[4], syt[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            sxx[o] = sm[o][0]; syy[o] = sm[o][1]; sxy[o] = sm[o][2]; sxt[o] = sm[o][3]; syt[o] = sm[o][4];
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int k = kb + o;
+            if (k >= M) break;
+            // flow_solver.sv:82-149: products keep their low 32 bits
+            auto lo = [](int p, int r) { return (int)((unsigned)p * (unsigned)r); };
+            const int det = (int)((unsigned)lo(sxx[o], syy[o]) - (unsigned)lo(sxy[o], sxy[o]));
+            const int nu = (int)((unsigned)lo(syy[o], sxt[o]) - (unsigned)lo(sxy[o], syt[o]));
+            const int nv = (int)((unsigned)lo(sxx[o], syt[o]) - (unsigned)lo(sxy[o], sxt[o]));
+            int fu = 0, fv = 0;
+            if (det > 1000 || det < -1000) {
+                const double rb = rtl_recip(det);
+                fu = (short)rtl_trunc_div((long long)nu * 128, det, rb);   // 39-bit quotient truncated towards zero, low 16 bits kept
+                fv = (short)rtl_trunc_div((long long)nv * 128, det, rb);
+                fu = fu > 1024 ? 1024 : (fu < -1024 ? -1024 : fu);
+                fv = fv > 1024 ? 1024 : (fv < -1024 ? -1024 : fv);
+            }
+            a.u[(size_t)b * M + k] = (short)fu;
+            a.v[(size_t)b * M + k] = (short)fv;
+            __builtin_amdgcn_sched_barrier(0);   // one element's 64-bit arithmetic at a time
+        }
     }
 }
 
