@@ -68,6 +68,49 @@ def profile_file(pattern: str, pairs: int, shape) -> dict | None:
     return best
 
 
+def live_traffic(pairs: int, shape, timeout_s: int = 240) -> dict | None:
+    """HBM bytes per launch of the dominant kernel, measured during this bench run: two child processes run the same
+    workload (tools/kbench.py: same plan, same synthetic frames) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
+    `... --pmc WRITE_SIZE` (separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; counters in units of
+    1024 B, FETCH_SIZE doubled on gfx950).  Returns None when rocprofv3 is missing, when this process is itself being
+    profiled, or when a pass fails -- the caller then falls back to the committed profiles/ measurement."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                       sys.executable, str(ROOT / "tools" / "kbench.py"), "--pairs", str(pairs), "--height", str(shape[0]),
+                       "--width", str(shape[1]), "--reps", "3"]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, timeout=timeout_s)
+                if r.returncode != 0:
+                    return None
+                rows = []
+                for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if "k_lkw<2, 1" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+                if not rows:
+                    return None
+                big = max(g for g, _ in rows)   # finest level = largest grid
+                vals = [v for g, v in rows if g == big]
+                out[counter] = (sum(vals) / len(vals), len(vals))
+    except Exception:
+        return None
+    fetch, write = out["FETCH_SIZE"][0] * 1024 * 2, out["WRITE_SIZE"][0] * 1024
+    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+            "launches_averaged": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +126,8 @@ def main() -> None:
     ap.add_argument("--cpu-sample-pairs", type=int, default=16, help="1080p pairs the CPU oracle is timed on (~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-pair", action="store_true", help="skip the informational batch-of-1 timing")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes; take roofline.traffic from profiles/")
     # rehearsal switches (a one-GPU box cannot host two RCCL ranks): gloo for the three small collectives, and
     # every rank on one device -- exercises the N > 1 code path end to end; the numbers of such a run mean nothing
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -171,13 +216,19 @@ def main() -> None:
         bytes_per_launch = model["finest_iteration_launch"] * B
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         tr = profile_file("hbm_traffic", B, (H, W))
+        live = None
+        if world == 1 and not args.no_live_traffic and args.levels == 3 and args.window == 5 and args.iters == 3:
+            live = live_traffic(B, (H, W))
         ib = profile_file("issue_bounds", B, (H, W))
         roofline = {"bound": "hbm", "kernel": "k_lkw<2,ITER> (fused LK iteration, finest level)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                    "traffic_source": (f"profiles/{tr['_file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
-                                       f"over this command (tools/measure_traffic.sh), not measurable inside the run") if tr else None,
+                    "traffic": live["hbm_bytes_per_launch"] if live else (tr["hbm_bytes_per_launch"] if tr else None),
+                    "traffic_source": ("measured during this run: child processes of bench.py ran the same workload (tools/kbench.py) "
+                                       "under rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, "
+                                       f"FETCH_SIZE x2 on gfx950); launches averaged {live['launches_averaged']}") if live else
+                                      ((f"profiles/{tr['_file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                                        f"over this command (tools/measure_traffic.sh); the live passes of this run were skipped or failed") if tr else None),
                     "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": bytes_per_launch,
                     "hbm_floor_us": round(bytes_per_launch / HBM_PEAK_GBS / 1e3, 1)}
         if ib:

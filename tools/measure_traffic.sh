@@ -10,8 +10,8 @@ R=$(pwd)
 OUT=$R/gpurun_out/traffic_$TAG
 rm -rf $OUT && mkdir -p $OUT/fetch $OUT/write
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-pair > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-pair > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-pair --no-live-traffic > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-pair --no-live-traffic > $OUT/write.log 2>&1
 cd $R
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, sys

@@ -14,7 +14,7 @@ mkdir -p gpurun_out profiles/${TAG}_pmc
 S=$R/gpurun_out/stats_$TAG
 rm -rf $S && mkdir -p $S
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $S -- python3 $R/bench.py --no-cpu-baseline --no-one-pair > $S/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $S -- python3 $R/bench.py --no-cpu-baseline --no-one-pair --no-live-traffic > $S/bench.log 2>&1
 cd $R
 grep -h '^{' $S/bench.log | tail -1 > profiles/${TAG}_bench_under_rocprof.json
 python3 tools/dominant_from_trace.py $S profiles/${TAG}_rocprofv3_dominant_kernel.json
