@@ -146,6 +146,21 @@ def write_flow_field(path, vectors: np.ndarray, width: int, height: int, region:
             f.write("%d %d %.6f %.6f\n" % (a, b, p, q))
 
 
+def compare_flow_field(path, vectors: np.ndarray, max_report: int = 10) -> Dict[str, object]:
+    """Pin the model against a simulator: compare a `flow_field.txt` written by an xsim run of
+    tb_optical_flow_top.sv (same frames) with the model's vectors, line for line (positions as filed, u / v as the
+    %.6f of the S8.7 value / 128).  Returns counts and the first differing lines."""
+    rows = [ln.split() for ln in Path(path).read_text().splitlines() if ln.strip() and not ln.startswith("#")]
+    x, y = filed_positions(vectors)
+    mine = [("%d" % a, "%d" % b, "%.6f" % p, "%.6f" % q) for a, b, p, q in zip(x, y, vectors[:, 2] / 128.0, vectors[:, 3] / 128.0)]
+    diffs = []
+    for i in range(min(len(rows), len(mine))):
+        if tuple(rows[i]) != mine[i]:
+            diffs.append((i, tuple(rows[i]), mine[i]))
+    return {"simulator_vectors": len(rows), "model_vectors": len(mine), "differing_lines": len(diffs) + abs(len(rows) - len(mine)),
+            "first_differences": diffs[:max_report], "equal": len(rows) == len(mine) and not diffs}
+
+
 def read_mem(path, width: int, height: int) -> np.ndarray:
     """a frame in the $readmemh format the frame buffer loads (one 2-digit hex pixel per line)"""
     vals = [int(t, 16) for t in Path(path).read_text().split() if not t.startswith("//")]
@@ -161,6 +176,9 @@ def main(argv=None) -> int:
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--output", default=None, help="write flow_field.txt here")
+    ap.add_argument("--compare", default=None, metavar="FLOW_FIELD_TXT",
+                    help="a flow_field.txt exported by an xsim run of tb/tb_optical_flow_top.sv on the same frames: "
+                         "compare it with the model line for line (exit status 1 if they differ)")
     args = ap.parse_args(argv)
 
     def load(p):
@@ -174,6 +192,13 @@ def main(argv=None) -> int:
     if args.output:
         write_flow_field(args.output, vec, args.width, args.height)
         print(f"\nExporting {len(vec)} flow vectors to {args.output}...")
+    if args.compare:
+        c = compare_flow_field(args.compare, vec)
+        print(f"\nsimulator: {c['simulator_vectors']} vectors, model: {c['model_vectors']}, differing lines: {c['differing_lines']}")
+        for i, sim, mod in c["first_differences"]:
+            print(f"  line {i}: simulator {' '.join(sim)} | model {' '.join(mod)}")
+        print("MODEL PINNED: equal to the simulator's export" if c["equal"] else "MODEL DIFFERS from the simulator's export")
+        return 0 if c["equal"] else 1
     return 0
 
 

@@ -101,6 +101,25 @@ def test_cli_on_mem_frames(golden_dir, tmp_path, capsys):
     assert (tmp_path / "ff.txt").read_text().startswith("# Optical flow field data\n# Format: x y u v\n# Image size: 320x240\n")
 
 
+def test_compare_with_a_simulator_export(golden_dir, tmp_path, capsys):
+    """the one command that pins the model once somebody has a simulator: --compare flow_field.txt"""
+    import rtl_golden_model as G
+
+    z = np.load(golden_dir / "rtl_frames.npz")
+    for i in (0, 1):
+        z[f"sinusoid__frame_0{i}"].tofile(tmp_path / f"frame_0{i}.bin")
+    args = [str(tmp_path / "frame_00.bin"), str(tmp_path / "frame_01.bin")]
+    assert G.main(args + ["--output", str(tmp_path / "sim.txt")]) == 0
+    assert G.main(args + ["--compare", str(tmp_path / "sim.txt")]) == 0
+    assert "MODEL PINNED" in capsys.readouterr().out
+    lines = (tmp_path / "sim.txt").read_text().splitlines()
+    lines[1000] = lines[1000].rsplit(" ", 1)[0] + " 0.507812"     # one vector off by a few LSBs
+    (tmp_path / "sim2.txt").write_text("\n".join(lines[:-2]) + "\n")   # and two vectors short, like the README's count
+    assert G.main(args + ["--compare", str(tmp_path / "sim2.txt")]) == 1
+    out = capsys.readouterr().out
+    assert "MODEL DIFFERS" in out and "differing lines: 3" in out
+
+
 def test_errors_are_loud():
     import _oflk
     import rtl_golden_model as G
