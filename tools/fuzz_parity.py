@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run: HIP path vs the CPU oracle on random shapes, parameters and data
 (development tool, run on the GPU box; the committed test-suite holds the fixed cases).
-Usage: python3 tools/fuzz_parity.py [cases] [seed]"""
+Usage: python3 tools/fuzz_parity.py [cases] [seed] | batch [cases] [seed] | rtl [cases] [seed]"""
 import os
 import sys
 from pathlib import Path
@@ -61,7 +61,50 @@ def batch_main(cases, seed):
     sys.exit(1 if bad else 0)
 
 
+def rtl_main(cases, seed):
+    """RTL-bit-accurate integer mode: GPU per-element flows vs the closed form of the RTL (oracle/rtl_model.py), and --
+    on the small cases -- the sampled vector sequence vs the cycle-by-cycle execution (oracle/rtl_cycle_sim.py)"""
+    import rtl_cycle_sim as S
+    import rtl_golden_model as G
+    import rtl_model as M
+
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for i in range(cases):
+        H, W = int(rng.integers(5, 513)), int(rng.integers(5, 1025))
+        if i % 4 == 0:
+            H, W = int(rng.integers(5, 40)), int(rng.integers(5, 48))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            f0, f1 = rng.integers(0, 256, (H, W)), rng.integers(0, 256, (H, W))
+        elif kind == 1:
+            f0 = rng.integers(0, 256, (H, W)); f1 = np.roll(f0, (int(rng.integers(-2, 3)), int(rng.integers(-3, 4))), (0, 1))
+        elif kind == 2:
+            f0 = rng.integers(120, 136, (H, W)); f1 = f0 + rng.integers(-1, 2, (H, W))
+        else:
+            yy, xx = np.mgrid[0:H, 0:W]
+            f0 = (128 + 120 * np.sin(xx / rng.uniform(1.5, 9)) * np.cos(yy / rng.uniform(1.5, 9))).astype(np.int64)
+            f1 = np.roll(f0, (1, 2), (0, 1))
+        f0, f1 = np.clip(f0, 0, 255).astype(np.uint8), np.clip(f1, 0, 255).astype(np.uint8)
+        st = G.rtl_flow_states(f0, f1)
+        gx, gy, gt, _ = M.gradient_stream(f0, f1)
+        valid, x, y, u, v = M.flow_states(gx, gy, gt, W)
+        ok = same(st["u"].astype(np.int64), u) and same(st["v"].astype(np.int64), v) and same(st["valid"], valid) and same(st["x"], x) and same(st["y"], y)
+        if ok and H * W <= 2000:
+            sim = np.array(S.simulate(f0.reshape(-1).astype(np.int64), f1.reshape(-1).astype(np.int64), W, H), np.int64).reshape(-1, 4)
+            vec = G.testbench_vectors(f0, f1)
+            ok = vec.shape == sim.shape and same(vec, sim)
+        if not ok:
+            bad += 1
+            print(f"MISMATCH rtl case {i}: H={H} W={W} kind={kind}", flush=True)
+        if i % 50 == 49:
+            print(f"{i + 1} rtl cases, {bad} mismatches", flush=True)
+    print(f"done: {cases} rtl cases, {bad} mismatches")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "rtl":
+        return rtl_main(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] == "batch":
         return batch_main(int(sys.argv[2]) if len(sys.argv) > 2 else 30, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
