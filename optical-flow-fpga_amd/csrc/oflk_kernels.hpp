@@ -2283,26 +2283,28 @@ struct RtlArgs {
     int H, W, B;
 };
 
-// floor(|a| / |b|) with the sign of a / b: Verilog's signed `/` truncates towards zero (flow_solver.sv:121-122).
-// |a| < 2^39, 1000 < |b| < 2^31.  `rb` ~ 1 / |b| to fp64 accuracy (shared by the two quotients of an element): the
-// product is within one of the integer quotient, the remainder settles it.
-__device__ __forceinline__ double rtl_recip(int b)
+// (num <<< 7) / det as Verilog's signed `/` computes it (truncation towards zero, flow_solver.sv:121-122), in fp64:
+// |num * 128| < 2^39 and 1000 < |det| < 2^31 are exact doubles, `rdet` ~ 1 / det to fp64 accuracy (shared by the two
+// quotients of an element), so trunc(a * rdet) is within one of the quotient; the remainder a - q det is an integer
+// below 2^33 in magnitude, which the fma returns exactly, and it settles the last unit.  |q| < 2^29 fits an int.
+__device__ __forceinline__ double rtl_recip(double d)
 {
-    const double d = (double)(b < 0 ? -(long long)b : (long long)b);
     double r = __builtin_amdgcn_rcp(d);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     return r;
 }
-__device__ __forceinline__ long long rtl_trunc_div(long long a, int b, double rb)
+__device__ __forceinline__ int rtl_trunc_div(int num, double det, double rdet)
 {
-    const unsigned long long ua = (unsigned long long)(a < 0 ? -a : a);
-    const unsigned long long ub = (unsigned long long)(b < 0 ? -(long long)b : (long long)b);
-    unsigned long long q = (unsigned long long)((double)ua * rb);
-    const long long r = (long long)ua - (long long)(q * ub);
-    if (r < 0) q -= 1;
-    else if ((unsigned long long)r >= ub) q += 1;
-    return ((a < 0) != (b < 0)) ? -(long long)q : (long long)q;
+    const double a = (double)num * 128.0;
+    double q = __builtin_trunc(a * rdet);
+    const double r = __builtin_fma(-q, det, a);          // exact
+    // the quotient truncates towards zero: the remainder must carry the sign of `a` and be smaller than |det|
+    const double ad = __builtin_fabs(det), s = (a < 0.0) != (det < 0.0) ? -1.0 : 1.0;
+    const double ra = a < 0.0 ? -r : r;                  // remainder measured in the direction of a
+    if (ra < 0.0) q -= s;                                // overshot: one step back towards zero
+    else if (ra >= ad) q += s;                           // undershot
+    return (int)q;
 }
 
 __global__ __launch_bounds__(256) void k_rtl_flow(RtlArgs a)
@@ -2445,9 +2447,9 @@ __global__ __launch_bounds__(256) void k_rtl_flow(RtlArgs a)
             const int nv = (int)((unsigned)lo(sxx[o], syt[o]) - (unsigned)lo(sxy[o], sxt[o]));
             int fu = 0, fv = 0;
             if (det > 1000 || det < -1000) {
-                const double rb = rtl_recip(det);
-                fu = (short)rtl_trunc_div((long long)nu * 128, det, rb);   // 39-bit quotient truncated towards zero, low 16 bits kept
-                fv = (short)rtl_trunc_div((long long)nv * 128, det, rb);
+                const double dd = (double)det, rd = rtl_recip(dd);
+                fu = (short)rtl_trunc_div(nu, dd, rd);   // 39-bit quotient truncated towards zero, low 16 bits kept
+                fv = (short)rtl_trunc_div(nv, dd, rd);
                 fu = fu > 1024 ? 1024 : (fu < -1024 ? -1024 : fu);
                 fv = fv > 1024 ? 1024 : (fv < -1024 ? -1024 : fv);
             }
