@@ -54,16 +54,17 @@ def algorithmic_bytes_per_pair(dims, levels: int, iters_run) -> dict:
             "finest_pyramid_launch": (2 * (4 * n[-1] + 4 * n[-2])) if levels > 1 else 0}
 
 
-def profile_file(pattern: str, pairs: int, shape) -> dict | None:
-    """The newest profiles/<tag>_<pattern>.json measured on this workload (PMC passes cannot run inside
-    the bench: tools/measure_traffic.sh, tools/issue_bounds.py)."""
+def profile_file(pattern: str, pairs: int, shape, any_pairs: bool = False) -> dict | None:
+    """The newest profiles/<tag>_<pattern>.json measured on this workload (tools/measure_traffic.sh,
+    tools/issue_bounds.py).  any_pairs: accept a file measured with another batch size of the same frame shape (the
+    caller scales per-launch quantities by the pair ratio: instruction counts of a launch are per pair)."""
     best = None
     for f in sorted((ROOT / "profiles").glob(f"*_{pattern}.json")):
         try:
             d = json.loads(f.read_text())
         except Exception:
             continue
-        if d.get("pairs") == pairs and d.get("shape") == list(shape):
+        if (any_pairs or d.get("pairs") == pairs) and d.get("shape") == list(shape):
             best = dict(d, _file=f.name)
     return best
 
@@ -219,7 +220,7 @@ def main() -> None:
         live = None
         if world == 1 and not args.no_live_traffic and args.levels == 3 and args.window == 5 and args.iters == 3:
             live = live_traffic(B, (H, W))
-        ib = profile_file("issue_bounds", B, (H, W))
+        ib = profile_file("issue_bounds", B, (H, W), any_pairs=True)
         roofline = {"bound": "hbm", "kernel": "k_lkw<2,ITER> (fused LK iteration, finest level)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -233,12 +234,14 @@ def main() -> None:
                     "hbm_floor_us": round(bytes_per_launch / HBM_PEAK_GBS / 1e3, 1)}
         if ib:
             # the instruction-side bounds of the same launch (the kernel's arithmetic is the reference's, op for op)
+            scale = B / float(ib["pairs"])   # the counters were taken on a launch of ib["pairs"] pairs; instructions are per pair
             for k in ("valu_pipe", "issue_cadence"):
-                roofline[k] = {"bound": k, "floor_us": ib[k]["floor_us"],
-                               "frac": round(ib[k]["floor_us"] / (avg_ms * 1e3), 4)}
+                roofline[k] = {"bound": k, "floor_us": round(ib[k]["floor_us"] * scale, 1),
+                               "frac": round(ib[k]["floor_us"] * scale / (avg_ms * 1e3), 4)}
             roofline["binding"] = ("none saturated: latency-bound at 4 waves per SIMD (wave state shares "
                                    f"{ib.get('wave_state_shares')}); see DESIGN.md section 5")
-            roofline["issue_bounds_source"] = f"profiles/{ib['_file']} (tools/issue_bounds.py)"
+            roofline["issue_bounds_source"] = (f"profiles/{ib['_file']} (tools/issue_bounds.py; SQ counters of a {ib['pairs']}-pair "
+                                               f"launch scaled to {B} pairs)")
     roofline_pyr = None
     pk = ktimes.get("pyr_down_fused")
     if pk and pk["launches"] and L > 1:

@@ -61,7 +61,8 @@ def main():
     run("configs[1]: 640x480 pair, single-scale 5x5", 1, 480, 640, 1, 5, 0, 200)
     run("configs[1] batched x256", 256, 480, 640, 1, 5, 0, 20)
     run("configs[2]: 1920x1080 pair, 3-level pyramidal 5x5 x3", 1, 1080, 1920, 3, 5, 3, 100)
-    run("configs[2] batched x32 (bench.py workload)", 32, 1080, 1920, 3, 5, 3, 20)
+    run("configs[2] batched x32 (the batch the kernel analysis of DESIGN.md section 5 is made on)", 32, 1080, 1920, 3, 5, 3, 20)
+    run("configs[2] batched x128 (bench.py workload)", 128, 1080, 1920, 3, 5, 3, 10)
     run("configs[3]: 3840x2160, one GPU's share of 64 pairs over 8 GPUs (8 pairs)", 8, 2160, 3840, 3, 5, 3, 10)
     run("configs[1] batched x256, uint8 frames (2 B/px of frame traffic)", 256, 480, 640, 1, 5, 0, 20, "u8")
     run("configs[2] batched x32, uint8 frames", 32, 1080, 1920, 3, 5, 3, 20, "u8")
