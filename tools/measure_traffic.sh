@@ -27,7 +27,9 @@ def per_launch(sub, counter):
     return sum(vals) / len(vals), len(vals), big
 fetch, nf, grid = per_launch("fetch", "FETCH_SIZE")
 write, nw, _ = per_launch("write", "WRITE_SIZE")
-res = {"kernel": "k_lkw<2, MODE_ITER> finest level", "pairs": 32, "shape": [1080, 1920], "grid_size": grid, "launches_averaged": [nf, nw],
+bench = [json.loads(l) for l in open(f"{out}/fetch.log") if l.startswith("{")][-1]   # the bench line of the profiled run
+pairs = bench["config"]["pairs_per_gpu_per_step"]
+res = {"kernel": "k_lkw<2, MODE_ITER> finest level", "pairs": pairs, "shape": [1080, 1920], "grid_size": grid, "launches_averaged": [nf, nw],
        "FETCH_SIZE_raw_units_1024B": fetch, "WRITE_SIZE_raw_units_1024B": write,
        "fetch_bytes_corrected_x2": fetch * 1024 * 2, "write_bytes": write * 1024,
        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
