@@ -695,18 +695,33 @@ OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, cons
         g.prev = d_prev; g.curr = d_curr; g.u = d_u; g.v = d_v;
         g.H = a.H; g.W = a.W; g.B = a.B;
         g.s_g = a.s_g; g.s_t = a.s_t; g.det_thr = a.det_thr;
-        const int outw = 64 - 2 * (hw + 1);
+        // two columns per lane for odd half windows (k_lk16d; 7x7: 79 VGPRs = 6 waves per SIMD, halo 6 %, 124 against
+        // 138 us at 8K; 11x11: 138 against 182), one column per lane for even ones (k_lk16s: 8 waves, halo 12.5 %);
+        // OFLK_LK16_COLS=1|2 forces a form (development switch)
+        static const int force_cols = getenv("OFLK_LK16_COLS") ? atoi(getenv("OFLK_LK16_COLS")) : 0;
+        const bool dbl = (hw & 1) && (force_cols ? force_cols == 2 : true);
+        const int outw = dbl ? 2 * (64 - 2 * ((hw + 1) / 2)) : 64 - 2 * (hw + 1);
         const long strips = ((long)a.W + outw - 1) / outw * a.B;
-        const long slots = 8192;
+        const long slots = dbl ? (hw == 1 ? 8192 : hw == 3 ? 6144 : 4096) : 8192;   // wave slots of the chip at the kernel's occupancy
         long segs = ((long)a.H + 63) / 64;
         const double rounds = (double)(strips * segs) / (double)slots;
         if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
+        else segs = std::max(segs, std::min(slots / std::max<long>(strips, 1), std::max<long>(1, a.H / 40)));   // fill the one round, >= 40 rows each
         segs = std::min<long>(segs, std::max<long>(1, a.H / 8));
         if (const char *e = getenv("OFLK_LK16_HS")) segs = std::max<long>(1, ((long)a.H + atol(e) - 1) / std::max<long>(1, atol(e)));
         g.Hs = (int)(((long)a.H + segs - 1) / segs);
         g.segs = (a.H + g.Hs - 1) / g.Hs;
         const long nwave = strips * g.segs;
         dim3 sgrid((unsigned)((nwave + 3) / 4)), sblock(256);
+        if (dbl) {
+            switch (hw) {
+                case 1: hipLaunchKernelGGL((k_lk16d<1>), sgrid, sblock, 0, s, g); break;
+                case 3: hipLaunchKernelGGL((k_lk16d<3>), sgrid, sblock, 0, s, g); break;
+                default: hipLaunchKernelGGL((k_lk16d<5>), sgrid, sblock, 0, s, g); break;
+            }
+            HIP_TRY(hipGetLastError());
+            return OFLK_OK;
+        }
         switch (hw) {
             case 1: hipLaunchKernelGGL((k_lk16s<1>), sgrid, sblock, 0, s, g); break;
             case 2: hipLaunchKernelGGL((k_lk16s<2>), sgrid, sblock, 0, s, g); break;

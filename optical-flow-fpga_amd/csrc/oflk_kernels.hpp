@@ -2259,6 +2259,169 @@ __global__ __launch_bounds__(256) void k_lk16s(Lk16sArgs a)
     }
 }
 
+// The same streaming arithmetic with TWO columns per lane (odd half windows: 3x3, 7x7, 11x11): a wave covers 128 columns
+// and produces 128 - 4 ceil(R/2) of them (7x7: 120, halo 6 % instead of 12.5 %), the five products are packed by
+// COLUMN pair {lo, hi}, and the horizontal sums need K + 1 wave shifts per side and register with K = (HW - 1) / 2:
+// lanes l-K .. l+K contribute both columns, lane l-K-1 its high and lane l+K+1 its low column.
+template <int HW>
+__global__ __launch_bounds__(256) void k_lk16d(Lk16sArgs a)
+{
+    static_assert(HW % 2 == 1, "two columns per lane: odd half windows");
+    constexpr int R = HW + 1, S = 2 * HW + 1, HL = R / 2, K = (HW - 1) / 2, OUTW = 2 * (64 - 2 * HL), PF = OFLK_LK16_PF, WPB = 4;
+    constexpr int SHR = 0x138, SHL = 0x130;   // DPP wave_shr:1 / wave_shl:1
+    const int lane = threadIdx.x & 63;
+    const int H = a.H, W = a.W;
+    const int strips = (W + OUTW - 1) / OUTW;
+    const int nwave = strips * a.segs * a.B;
+    const int nblk = (nwave + WPB - 1) / WPB;
+    const int task = __builtin_amdgcn_readfirstlane(xcd_tile_index(blockIdx.x, nblk) * WPB + (int)(threadIdx.x >> 6));
+    if (task >= nwave) return;
+    const int b = task / (strips * a.segs);
+    const int t = task - b * (strips * a.segs);
+    const int seg = t / strips, strip = t - seg * strips;
+    const int xw = strip * OUTW - 2 * HL;          // first column of the wave (uniform)
+    const int x = xw + 2 * lane;                   // the lane's low column
+    const bool vec = xw >= 0 && xw + 128 <= W && (W & 1) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.curr) | reinterpret_cast<uintptr_t>(a.u) |
+                       reinterpret_cast<uintptr_t>(a.v)) & 7u) == 0;   // uniform: one 8-byte access per lane and row
+    const unsigned cb0 = 4u * (unsigned)min(max(x, 0), W - 1), cb1 = 4u * (unsigned)min(max(x + 1, 0), W - 1);
+    const int ys = seg * a.Hs, ye = min(ys + a.Hs, H);
+    const size_t plane = (size_t)H * (size_t)W;
+    const float *__restrict__ prev = a.prev + (size_t)b * plane;
+    const float *__restrict__ curr = a.curr + (size_t)b * plane;
+    float *__restrict__ ou = a.u + (size_t)b * plane;
+    float *__restrict__ ov = a.v + (size_t)b * plane;
+    const float ha = 0.5f * a.s_g, st = a.s_t;
+    const bool lane_out = lane >= HL && lane < 64 - HL;
+    const bool in0 = x >= HW && x < W - HW, in1 = x + 1 >= HW && x + 1 < W - HW;   // columns with a full window
+
+    auto row_off = [&](int r) { return (size_t)min(max(r, 0), H - 1) * (size_t)W; };   // "symm" ring
+    auto load2 = [&](const float *base, size_t o) {
+        if (vec) return ld_off<float2>(base + o, cb0);
+        return make_float2(ld_off<float>(base + o, cb0), ld_off<float>(base + o, cb1));
+    };
+    const int r0 = ys - R + 2;
+    float2 a0, a1, it1;
+    {
+        const size_t o0 = row_off(r0 - 2), o1 = row_off(r0 - 1);
+        const float2 p0 = load2(prev, o0), q0 = load2(curr, o0), p1 = load2(prev, o1), q1 = load2(curr, o1);
+        a0 = make_float2((p0.x + q0.x) * ha, (p0.y + q0.y) * ha);
+        a1 = make_float2((p1.x + q1.x) * ha, (p1.y + q1.y) * ha);
+        it1 = make_float2((p1.x - q1.x) * st, (p1.y - q1.y) * st);
+    }
+    float2 pb[PF], qb[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        const size_t o = row_off(r0 + k);
+        pb[k] = load2(prev, o);
+        qb[k] = load2(curr, o);
+    }
+    const h2 zero2 = h2{(_Float16)0.0f, (_Float16)0.0f};
+    h2 ring[S][5], fw[5] = {zero2, zero2, zero2, zero2, zero2};   // vertical sums as in k_lk16s (blocks aligned to absolute rows)
+#pragma unroll
+    for (int j = 0; j < S; j++)
+#pragma unroll
+        for (int pl = 0; pl < 5; pl++) ring[j][pl] = zero2;
+
+    const int n_it = ye - ys + 2 * HW;
+    const int j0 = ((r0 - 1) % S + S) % S;
+    for (int i0 = -j0; i0 < n_it; i0 += S) {
+        static_for(std::make_integer_sequence<int, S>{}, [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int i = i0 + j;
+            if (i < 0 || i >= n_it) return;   // uniform
+            const int r = r0 + i;
+            const float2 p = pb[0], q = qb[0];
+#pragma unroll
+            for (int k = 0; k + 1 < PF; k++) {
+                pb[k] = pb[k + 1];
+                qb[k] = qb[k + 1];
+            }
+            {
+                const size_t o = row_off(r + PF);
+                pb[PF - 1] = load2(prev, o);
+                qb[PF - 1] = load2(curr, o);
+            }
+            const float2 a2 = make_float2((p.x + q.x) * ha, (p.y + q.y) * ha), itn = make_float2((p.x - q.x) * st, (p.y - q.y) * st);
+            // Sobel/8 of row r - 1: column 2l has its neighbours in lane l-1 (high) and lane l (high); column 2l+1 in lane l
+            // (low) and lane l+1 (low)
+            const float smx = (a0.x + a2.x) + 2.0f * a1.x, smy = (a0.y + a2.y) + 2.0f * a1.y;
+            const float dfx = a0.x - a2.x, dfy = a0.y - a2.y;
+            const float ix0 = (wave_shift<SHR>(smy) - smy) * 0.125f, ix1 = (smx - wave_shift<SHL>(smx)) * 0.125f;
+            const float iy0 = ((wave_shift<SHR>(dfy) + dfy) + 2.0f * dfx) * 0.125f, iy1 = ((dfx + wave_shift<SHL>(dfx)) + 2.0f * dfy) * 0.125f;
+            const h2 hx = h2{(_Float16)ix0, (_Float16)ix1}, hy = h2{(_Float16)iy0, (_Float16)iy1}, ht = h2{(_Float16)it1.x, (_Float16)it1.y};
+            h2 c[5];
+            c[0] = hx * hx;   // IxIx of the two columns
+            c[1] = hy * hy;
+            c[2] = hx * hy;
+            c[3] = hx * ht;
+            c[4] = hy * ht;
+            a0 = a1; a1 = a2; it1 = itn;
+            h2 vs[5];
+#pragma unroll
+            for (int pl = 0; pl < 5; pl++) {
+                fw[pl] = j == 0 ? c[pl] : fw[pl] + c[pl];
+                vs[pl] = j == S - 1 ? fw[pl] : ring[(j + 1) % S][pl] + fw[pl];
+                ring[j][pl] = c[pl];
+            }
+            if constexpr (j == S - 1) {
+#pragma unroll
+                for (int k = S - 2; k >= 1; k--)
+#pragma unroll
+                    for (int pl = 0; pl < 5; pl++) ring[k][pl] = ring[k][pl] + ring[k + 1][pl];
+            }
+            const int o = r - R;
+            if (o >= ys) {
+                float sum[5][2];
+#pragma unroll
+                for (int pl = 0; pl < 5; pl++) {
+                    h2 l = vs[pl], rr = vs[pl], m = vs[pl];
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        l = wave_shift<SHR>(l);
+                        rr = wave_shift<SHL>(rr);
+                        m = m + (l + rr);
+                    }
+                    l = wave_shift<SHR>(l);     // lane l-K-1: its high column
+                    rr = wave_shift<SHL>(rr);   // lane l+K+1: its low column
+                    const unsigned mu = __builtin_bit_cast(unsigned, m);
+                    const h2 msw = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(mu, mu, 16));                        // {hi, lo}
+                    const h2 e = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, rr), __builtin_bit_cast(unsigned, l), 16));   // {l.hi, rr.lo}
+                    const h2 out = (m + msw) + e;
+                    sum[pl][0] = (float)out.x;
+                    sum[pl][1] = (float)out.y;
+                }
+                float uu[2], vv[2];
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) {
+                    const float Sxx = sum[0][cc], Syy = sum[1][cc], Sxy = sum[2][cc], Sxt = sum[3][cc], Syt = sum[4][cc];
+                    const float det = Sxx * Syy - Sxy * Sxy;
+                    const float inv = __builtin_amdgcn_rcpf(det) * 2.0f;   // s_g / s_t = 2
+                    const bool solve = fabsf(det) > a.det_thr && (cc ? in1 : in0) && o >= HW && o < H - HW;   // borders stay 0 (:101-108)
+                    uu[cc] = solve ? (Sxy * Syt - Syy * Sxt) * inv : 0.0f;
+                    vv[cc] = solve ? (Sxy * Sxt - Sxx * Syt) * inv : 0.0f;
+                }
+                if (lane_out) {
+                    const size_t orow = (size_t)o * (size_t)W;
+                    if (vec) {
+                        st_off<float2>(ou + orow, 4u * (unsigned)x, make_float2(uu[0], uu[1]));
+                        st_off<float2>(ov + orow, 4u * (unsigned)x, make_float2(vv[0], vv[1]));
+                    } else {
+                        if (x >= 0 && x < W) {
+                            st_off<float>(ou + orow, 4u * (unsigned)x, uu[0]);
+                            st_off<float>(ov + orow, 4u * (unsigned)x, vv[0]);
+                        }
+                        if (x + 1 >= 0 && x + 1 < W) {
+                            st_off<float>(ou + orow, 4u * (unsigned)(x + 1), uu[1]);
+                            st_off<float>(ov + orow, 4u * (unsigned)(x + 1), vv[1]);
+                        }
+                    }
+                }
+            }
+        });
+    }
+}
+
 // ---------------------------------------------------------------------------
 // RTL-bit-accurate integer mode: what the reference's single-scale RTL computes
 // for a frame pair, per element k of its gradient stream -- rtl/common/line_buffer_5x5.sv:75-151 (window

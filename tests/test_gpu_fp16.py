@@ -141,6 +141,35 @@ def test_fp16_other_windows_and_ragged_shapes():
                 assert np.median(epe) <= 0.1, (H, W, win, float(np.median(epe)))
 
 
+def test_fp16_one_and_two_columns_per_lane_agree(suite):
+    """the streaming kernel exists with one column per lane (k_lk16s, every window) and with two (k_lk16d, odd half
+    windows: the default for 3x3, 7x7, 11x11).  Same arithmetic contract; the packed sums are added in a different
+    order across columns, so the flows agree to fp16 rounding of the window sums, not bit for bit.  The forcing switch
+    is read once per process: the one-column form runs in a child process."""
+    import subprocess
+    import sys
+
+    import lucas_kanade_core as K
+
+    p = suite["frame_0"].astype(np.float32)
+    c = suite["frame_1__rotate_medium"].astype(np.float32)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import lucas_kanade_core as K; z = np.load(%r); "
+            "u, v = K.lucas_kanade_single_scale_fp16(z['frame_0'].astype(np.float32), z['frame_1__rotate_medium'].astype(np.float32), 7, 255.0); "
+            "np.save(sys.argv[1], np.stack([u, v]))")
+    out = ROOT / "gpurun_out" / "fp16_cols1.npy"
+    out.parent.mkdir(exist_ok=True)
+    env = dict(os.environ, OFLK_LK16_COLS="1")
+    subprocess.run([sys.executable, "-c", code % (str(ROOT / "optical-flow-fpga_amd" / "python"), str(ROOT / "tests" / "golden" / "patterns_320x240.npz")), str(out)],
+                   check=True, env=env, timeout=300)
+    u1, v1 = np.load(out)
+    u2, v2 = K.lucas_kanade_single_scale_fp16(p, c, 7, 255.0)
+    ue, ve = K.lucas_kanade_single_scale(p, c, 7)
+    for hu, hv in ((u1, v1), (u2, v2)):
+        assert np.median(np.sqrt((hu.astype(np.float64) - ue) ** 2 + (hv.astype(np.float64) - ve) ** 2)) <= TOL_MEDIAN
+    assert np.median(np.sqrt((u1.astype(np.float64) - u2) ** 2 + (v1.astype(np.float64) - v2) ** 2)) <= TOL_MEDIAN
+    out.unlink()
+
+
 def test_fp16_tiled_form_agrees_with_the_streaming_form(suite, monkeypatch):
     """the library holds two kernels for this mode: the streaming one (default: one wave per 64-column strip,
     everything in registers) and the LDS-tiled one (OFLK_LK16_TILED=1, kept for its tile sizing, DESIGN.md);
@@ -176,7 +205,9 @@ def test_fp16_strip_and_segment_seams():
 
     rng = np.random.default_rng(11)
     dev = torch.device("cuda", 0)
-    for (B, H, W, win) in ((2, 90, 56, 7), (1, 77, 113, 7), (3, 41, 58 * 3 + 1, 5), (1, 200, 129, 3)):
+    # 7x7 / 3x3 / 11x11 run two columns per lane (strips of 120 / 124 / 116 columns), 5x5 / 9x9 one (58 / 54)
+    for (B, H, W, win) in ((2, 90, 56, 7), (1, 77, 113, 7), (3, 41, 58 * 3 + 1, 5), (1, 200, 129, 3), (2, 60, 241, 7), (1, 50, 121, 7),
+                           (1, 64, 250, 11), (2, 33, 117, 9), (1, 45, 375, 3)):
         a = rng.integers(0, 256, (B, H, W)).astype(np.float32)
         b = np.roll(a, (1, -1), (1, 2))
         ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
