@@ -714,11 +714,19 @@ OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, cons
         const long nwave = strips * g.segs;
         dim3 sgrid((unsigned)((nwave + 3) / 4)), sblock(256);
         if (dbl) {
+            auto al8 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
+            const bool vec8 = (a.W & 1) == 0 && a.W >= 2 && al8(d_prev) && al8(d_curr) && al8(d_u) && al8(d_v);   // 8-byte column pairs
+#define OFLK_LAUNCH_LK16D(HWV)                                                                 \
+    do {                                                                                       \
+        if (vec8) hipLaunchKernelGGL((k_lk16d<HWV, true>), sgrid, sblock, 0, s, g);            \
+        else hipLaunchKernelGGL((k_lk16d<HWV, false>), sgrid, sblock, 0, s, g);                \
+    } while (0)
             switch (hw) {
-                case 1: hipLaunchKernelGGL((k_lk16d<1>), sgrid, sblock, 0, s, g); break;
-                case 3: hipLaunchKernelGGL((k_lk16d<3>), sgrid, sblock, 0, s, g); break;
-                default: hipLaunchKernelGGL((k_lk16d<5>), sgrid, sblock, 0, s, g); break;
+                case 1: OFLK_LAUNCH_LK16D(1); break;
+                case 3: OFLK_LAUNCH_LK16D(3); break;
+                default: OFLK_LAUNCH_LK16D(5); break;
             }
+#undef OFLK_LAUNCH_LK16D
             HIP_TRY(hipGetLastError());
             return OFLK_OK;
         }

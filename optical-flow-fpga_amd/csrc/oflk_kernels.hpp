@@ -2263,7 +2263,9 @@ __global__ __launch_bounds__(256) void k_lk16s(Lk16sArgs a)
 // and produces 128 - 4 ceil(R/2) of them (7x7: 120, halo 6 % instead of 12.5 %), the five products are packed by
 // COLUMN pair {lo, hi}, and the horizontal sums need K + 1 wave shifts per side and register with K = (HW - 1) / 2:
 // lanes l-K .. l+K contribute both columns, lane l-K-1 its high and lane l+K+1 its low column.
-template <int HW>
+// VEC (W even, planes 8-byte aligned: the host checks): every lane moves its column pair with one 8-byte access; pairs
+// that lie outside the frame (halo lanes of the first and last strip) take the edge pair and repeat its edge column.
+template <int HW, bool VEC>
 __global__ __launch_bounds__(256) void k_lk16d(Lk16sArgs a)
 {
     static_assert(HW % 2 == 1, "two columns per lane: odd half windows");
@@ -2281,10 +2283,8 @@ __global__ __launch_bounds__(256) void k_lk16d(Lk16sArgs a)
     const int seg = t / strips, strip = t - seg * strips;
     const int xw = strip * OUTW - 2 * HL;          // first column of the wave (uniform)
     const int x = xw + 2 * lane;                   // the lane's low column
-    const bool vec = xw >= 0 && xw + 128 <= W && (W & 1) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.curr) | reinterpret_cast<uintptr_t>(a.u) |
-                       reinterpret_cast<uintptr_t>(a.v)) & 7u) == 0;   // uniform: one 8-byte access per lane and row
     const unsigned cb0 = 4u * (unsigned)min(max(x, 0), W - 1), cb1 = 4u * (unsigned)min(max(x + 1, 0), W - 1);
+    const unsigned cbp = 4u * (unsigned)min(max(x, 0), max(W - 2, 0));   // VEC: the pair's (even) byte offset, clamped into the row
     const int ys = seg * a.Hs, ye = min(ys + a.Hs, H);
     const size_t plane = (size_t)H * (size_t)W;
     const float *__restrict__ prev = a.prev + (size_t)b * plane;
@@ -2297,8 +2297,12 @@ __global__ __launch_bounds__(256) void k_lk16d(Lk16sArgs a)
 
     auto row_off = [&](int r) { return (size_t)min(max(r, 0), H - 1) * (size_t)W; };   // "symm" ring
     auto load2 = [&](const float *base, size_t o) {
-        if (vec) return ld_off<float2>(base + o, cb0);
-        return make_float2(ld_off<float>(base + o, cb0), ld_off<float>(base + o, cb1));
+        if constexpr (VEC) {
+            const float2 w = ld_off<float2>(base + o, cbp);
+            return x < 0 ? make_float2(w.x, w.x) : (x >= W ? make_float2(w.y, w.y) : w);   // "symm": the edge column repeats
+        } else {
+            return make_float2(ld_off<float>(base + o, cb0), ld_off<float>(base + o, cb1));
+        }
     };
     const int r0 = ys - R + 2;
     float2 a0, a1, it1;
@@ -2403,9 +2407,11 @@ __global__ __launch_bounds__(256) void k_lk16d(Lk16sArgs a)
                 }
                 if (lane_out) {
                     const size_t orow = (size_t)o * (size_t)W;
-                    if (vec) {
-                        st_off<float2>(ou + orow, 4u * (unsigned)x, make_float2(uu[0], uu[1]));
-                        st_off<float2>(ov + orow, 4u * (unsigned)x, make_float2(vv[0], vv[1]));
+                    if constexpr (VEC) {
+                        if (x < W) {   // x >= 0 for output lanes; W even: the pair is inside
+                            st_off<float2>(ou + orow, 4u * (unsigned)x, make_float2(uu[0], uu[1]));
+                            st_off<float2>(ov + orow, 4u * (unsigned)x, make_float2(vv[0], vv[1]));
+                        }
                     } else {
                         if (x >= 0 && x < W) {
                             st_off<float>(ou + orow, 4u * (unsigned)x, uu[0]);
