@@ -695,14 +695,14 @@ OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, cons
         g.prev = d_prev; g.curr = d_curr; g.u = d_u; g.v = d_v;
         g.H = a.H; g.W = a.W; g.B = a.B;
         g.s_g = a.s_g; g.s_t = a.s_t; g.det_thr = a.det_thr;
-        // two columns per lane for odd half windows (k_lk16d; 7x7: 79 VGPRs = 6 waves per SIMD, halo 6 %, 124 against
-        // 138 us at 8K; 11x11: 138 against 182), one column per lane for even ones (k_lk16s: 8 waves, halo 12.5 %);
-        // OFLK_LK16_COLS=1|2 forces a form (development switch)
+        // two columns per lane (k_lk16d; 7x7: 77 VGPRs = 6 waves per SIMD, halo 6 %, 116-128 against 124-144 us at 8K;
+        // 11x11: 138 against 182); OFLK_LK16_COLS=1 runs the one-column form instead (k_lk16s: 8 waves, halo 9-12.5 %;
+        // development switch)
         static const int force_cols = getenv("OFLK_LK16_COLS") ? atoi(getenv("OFLK_LK16_COLS")) : 0;
-        const bool dbl = (hw & 1) && (force_cols ? force_cols == 2 : true);
-        const int outw = dbl ? 2 * (64 - 2 * ((hw + 1) / 2)) : 64 - 2 * (hw + 1);
+        const bool dbl = force_cols != 1;
+        const int outw = dbl ? 2 * (64 - 2 * ((hw + 2) / 2)) : 64 - 2 * (hw + 1);
         const long strips = ((long)a.W + outw - 1) / outw * a.B;
-        const long slots = dbl ? (hw == 1 ? 8192 : hw == 3 ? 6144 : 4096) : 8192;   // wave slots of the chip at the kernel's occupancy
+        const long slots = dbl ? (hw <= 2 ? 8192 : hw == 3 ? 6144 : hw == 4 ? 5120 : 4096) : 8192;   // wave slots of the chip at the kernel's occupancy (8 / 8 / 6 / 5 / 4 waves per SIMD)
         long segs = ((long)a.H + 63) / 64;
         const double rounds = (double)(strips * segs) / (double)slots;
         if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
@@ -723,8 +723,11 @@ OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, cons
     } while (0)
             switch (hw) {
                 case 1: OFLK_LAUNCH_LK16D(1); break;
+                case 2: OFLK_LAUNCH_LK16D(2); break;
                 case 3: OFLK_LAUNCH_LK16D(3); break;
-                default: OFLK_LAUNCH_LK16D(5); break;
+                case 4: OFLK_LAUNCH_LK16D(4); break;
+                case 5: OFLK_LAUNCH_LK16D(5); break;
+                default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
             }
 #undef OFLK_LAUNCH_LK16D
             HIP_TRY(hipGetLastError());

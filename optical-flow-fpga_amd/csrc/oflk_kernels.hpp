@@ -2259,17 +2259,19 @@ __global__ __launch_bounds__(256) void k_lk16s(Lk16sArgs a)
     }
 }
 
-// The same streaming arithmetic with TWO columns per lane (odd half windows: 3x3, 7x7, 11x11): a wave covers 128 columns
-// and produces 128 - 4 ceil(R/2) of them (7x7: 120, halo 6 % instead of 12.5 %), the five products are packed by
-// COLUMN pair {lo, hi}, and the horizontal sums need K + 1 wave shifts per side and register with K = (HW - 1) / 2:
-// lanes l-K .. l+K contribute both columns, lane l-K-1 its high and lane l+K+1 its low column.
+// The same streaming arithmetic with TWO columns per lane: a wave covers 128 columns and produces 128 - 4 ceil(R/2) of
+// them (5x5 and 7x7: 120, halo 6 % instead of 9 - 12.5 %), the five products are packed by COLUMN pair {lo, hi}, and the
+// horizontal sums need ceil(HW/2) wave shifts per side and register.  Odd HW (K = (HW-1)/2): lanes l-K .. l+K
+// contribute both columns, lane l-K-1 its high and lane l+K+1 its low column.  Even HW (K = HW/2): lanes l-K+1 .. l+K-1
+// contribute both columns to both outputs; lane l-K gives both columns to the low output and its high column to the high
+// output, lane l+K its low column to the low output and both to the high one.
 // VEC (W even, planes 8-byte aligned: the host checks): every lane moves its column pair with one 8-byte access; pairs
 // that lie outside the frame (halo lanes of the first and last strip) take the edge pair and repeat its edge column.
 template <int HW, bool VEC>
 __global__ __launch_bounds__(256) void k_lk16d(Lk16sArgs a)
 {
-    static_assert(HW % 2 == 1, "two columns per lane: odd half windows");
-    constexpr int R = HW + 1, S = 2 * HW + 1, HL = R / 2, K = (HW - 1) / 2, OUTW = 2 * (64 - 2 * HL), PF = OFLK_LK16_PF, WPB = 4;
+    constexpr bool ODD = HW % 2 == 1;
+    constexpr int R = HW + 1, S = 2 * HW + 1, HL = (R + 1) / 2, K = ODD ? (HW - 1) / 2 : HW / 2, OUTW = 2 * (64 - 2 * HL), PF = OFLK_LK16_PF, WPB = 4;
     constexpr int SHR = 0x138, SHL = 0x130;   // DPP wave_shr:1 / wave_shl:1
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
@@ -2379,19 +2381,34 @@ __global__ __launch_bounds__(256) void k_lk16d(Lk16sArgs a)
                 float sum[5][2];
 #pragma unroll
                 for (int pl = 0; pl < 5; pl++) {
-                    h2 l = vs[pl], rr = vs[pl], m = vs[pl];
+                    auto swap = [](h2 q) { const unsigned w = __builtin_bit_cast(unsigned, q); return __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(w, w, 16)); };   // {hi, lo}
+                    auto hi_lo = [](h2 p0, h2 p1) {   // {p0.hi, p1.lo}
+                        return __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, p1), __builtin_bit_cast(unsigned, p0), 16));
+                    };
+                    h2 l = vs[pl], rr = vs[pl], m = vs[pl], out;
+                    if constexpr (ODD) {
 #pragma unroll
-                    for (int k = 0; k < K; k++) {
-                        l = wave_shift<SHR>(l);
-                        rr = wave_shift<SHL>(rr);
-                        m = m + (l + rr);
+                        for (int k = 0; k < K; k++) {
+                            l = wave_shift<SHR>(l);
+                            rr = wave_shift<SHL>(rr);
+                            m = m + (l + rr);
+                        }
+                        l = wave_shift<SHR>(l);     // lane l-K-1: its high column
+                        rr = wave_shift<SHL>(rr);   // lane l+K+1: its low column
+                        out = (m + swap(m)) + hi_lo(l, rr);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k + 1 < K; k++) {
+                            l = wave_shift<SHR>(l);
+                            rr = wave_shift<SHL>(rr);
+                            m = m + (l + rr);
+                        }
+                        l = wave_shift<SHR>(l);     // lane l-K
+                        rr = wave_shift<SHL>(rr);   // lane l+K
+                        const h2 e1 = hi_lo(l, rr);                                              // {l.hi, rr.lo}: in both outputs
+                        const h2 e2 = __builtin_bit_cast(h2, (__builtin_bit_cast(unsigned, l) & 0xFFFFu) | (__builtin_bit_cast(unsigned, rr) & 0xFFFF0000u));   // {l.lo, rr.hi}
+                        out = ((m + swap(m)) + (e1 + swap(e1))) + e2;
                     }
-                    l = wave_shift<SHR>(l);     // lane l-K-1: its high column
-                    rr = wave_shift<SHL>(rr);   // lane l+K+1: its low column
-                    const unsigned mu = __builtin_bit_cast(unsigned, m);
-                    const h2 msw = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(mu, mu, 16));                        // {hi, lo}
-                    const h2 e = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(__builtin_bit_cast(unsigned, rr), __builtin_bit_cast(unsigned, l), 16));   // {l.hi, rr.lo}
-                    const h2 out = (m + msw) + e;
                     sum[pl][0] = (float)out.x;
                     sum[pl][1] = (float)out.y;
                 }

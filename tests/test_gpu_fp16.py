@@ -142,8 +142,8 @@ def test_fp16_other_windows_and_ragged_shapes():
 
 
 def test_fp16_one_and_two_columns_per_lane_agree(suite):
-    """the streaming kernel exists with one column per lane (k_lk16s, every window) and with two (k_lk16d, odd half
-    windows: the default for 3x3, 7x7, 11x11).  Same arithmetic contract; the packed sums are added in a different
+    """the streaming kernel exists with two columns per lane (k_lk16d, the one that runs) and with one (k_lk16s,
+    OFLK_LK16_COLS=1).  Same arithmetic contract; the packed sums are added in a different
     order across columns, so the flows agree to fp16 rounding of the window sums, not bit for bit.  The forcing switch
     is read once per process: the one-column form runs in a child process."""
     import subprocess
@@ -205,7 +205,7 @@ def test_fp16_strip_and_segment_seams():
 
     rng = np.random.default_rng(11)
     dev = torch.device("cuda", 0)
-    # 7x7 / 3x3 / 11x11 run two columns per lane (strips of 120 / 124 / 116 columns), 5x5 / 9x9 one (58 / 54)
+    # two columns per lane: strips of 124 (3x3), 120 (5x5, 7x7), 116 (9x9, 11x11) columns
     for (B, H, W, win) in ((2, 90, 56, 7), (1, 77, 113, 7), (3, 41, 58 * 3 + 1, 5), (1, 200, 129, 3), (2, 60, 241, 7), (1, 50, 121, 7),
                            (1, 64, 250, 11), (2, 33, 117, 9), (1, 45, 375, 3)):
         a = rng.integers(0, 256, (B, H, W)).astype(np.float32)
