@@ -63,6 +63,6 @@ grep -h '^{' gpurun_out/bench_4k64_$TAG.log | tail -1 > profiles/${TAG}_bench_4k
 python3 bench.py > gpurun_out/bench_$TAG.log 2>&1
 grep -h '^{' gpurun_out/bench_$TAG.log | tail -1 > profiles/${TAG}_bench.json
 cat profiles/${TAG}_bench.json
+python3 tools/profiles_summary.py $TAG || true
 # gpurun merges only gpurun_out/ back to the build container: leave a copy of everything there
 rm -rf gpurun_out/profiles_$TAG && mkdir -p gpurun_out/profiles_$TAG && cp -r profiles/${TAG}_* gpurun_out/profiles_$TAG/
-python3 tools/profiles_summary.py $TAG || true
