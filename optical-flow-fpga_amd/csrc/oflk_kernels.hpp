@@ -24,6 +24,9 @@
 // 5 flow_out = flow_in (the flow stays 0: identity warp, so the other ablations keep a sane gather pattern),
 // 6 no fp64 tap sums, 7 no fp64 tap coordinates / weights, 8 no gathers of curr (warped = prev),
 // 9 no re-read of the flow in the epilogue, 10 no loads of the flow in stage 1.  Results are wrong.
+#ifndef OFLK_PYR_PAIRS
+#define OFLK_PYR_PAIRS 1   // k_pyr_down: interior float32 tiles staged as column pairs (8-byte loads)
+#endif
 #ifndef OFLK_LK16_ABL
 #define OFLK_LK16_ABL 0   // timing experiments on k_lk16s (wrong results): 1 no horizontal shifts, 2 no solve, 4 no stores, 8 no vertical sums, 16 no Sobel shifts
 #endif
@@ -1516,6 +1519,32 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
         const int ybase = ylo - 8, xbase = xlo - 8;
         const int r0 = tid / kPIW, c0 = tid - r0 * kPIW;
         float vals[NA];
+        bool staged = false;
+        if constexpr (sizeof(PIX) == 4 && (OFLK_ABLATE & 4096) == 0 && OFLK_PYR_PAIRS) {
+            if (ybase >= 0 && ybase + kPIH <= H && xbase >= 0 && xbase + kPIW <= W) {
+                // interior tile, float32 frames: column PAIRS, one 8-byte load and one 8-byte LDS write each (the tile is
+                // 82 = 2 x 41 columns wide; 2050 pairs = 8 per thread + 2)
+                constexpr int PWD = kPIW / 2, NPR = kPIH * PWD, NB = (NPR + 255) / 256, QB = 256 / PWD, RB = 256 % PWD;
+                static_assert(kPIW % 2 == 0, "pairs");
+                float2 pv[NB];
+                int r = tid / PWD, c = tid - r * PWD;
+                unsigned off = (unsigned)__mul24(ybase + r, W) + (unsigned)(xbase + 2 * c);
+                const unsigned step = (unsigned)__mul24(QB, W) + 2 * RB, wrap = (unsigned)(W - kPIW);
+                int cc = c;
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    if ((k + 1) * 256 <= NPR || tid + k * 256 < NPR) pv[k] = ld_off<float2>(src, off * 4u);
+                    off += step; cc += RB;
+                    if (cc >= PWD) { cc -= PWD; off += wrap; }
+                }
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+                    if ((k + 1) * 256 <= NPR || tid + k * 256 < NPR) reinterpret_cast<float2 *>(s_in)[tid + k * 256] = pv[k];   // pair e -> cells 2e, 2e+1
+                staged = true;
+            }
+        }
+        if (staged) {
+        } else
         if constexpr ((OFLK_ABLATE & 4096) != 0) {   // timing experiment: no global loads
 #pragma unroll
             for (int k = 0; k < NA; k++) vals[k] = (float)(tid + k);
@@ -1549,9 +1578,11 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
                 if (c >= kPIW) { c -= kPIW; r += 1; }
             }
         }
+        if (!staged) {
 #pragma unroll
-        for (int k = 0; k < NA; k++)
-            if (k < NA - 1 || tid < NLAST) s_in[tid + k * 256] = vals[k];
+            for (int k = 0; k < NA; k++)
+                if (k < NA - 1 || tid < NLAST) s_in[tid + k * 256] = vals[k];
+        }
     }
     __syncthreads();
 
