@@ -182,6 +182,17 @@ __device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v)
     *reinterpret_cast<T *>(static_cast<char *>(base) + byte_off) = v;
 }
 
+// a wave-uniform pointer pinned to a scalar register pair: a load at `scalar_ptr(row) + lane offset` then takes the
+// scalar-base form (SGPR pair + 32-bit VGPR offset) instead of 64-bit address arithmetic on the vector ALU
+template <class T>
+__device__ __forceinline__ const T *scalar_ptr(const T *p)
+{
+    typedef const T __attribute__((address_space(1))) *gptr;   // keep the global address space through the asm
+    gptr g = (gptr)p;
+    asm volatile("" : "+s"(g));
+    return (const T *)g;
+}
+
 // Frame pixels are float32 (what the reference's callers hand over) or uint8 (its on-disk frame
 // format, generate_test_suite.py:259-261): PIX selects the element type a kernel reads; the uint8 ->
 // float32 conversion (optical_flow_verifier.py:61-65) is exact, so both give the same values.
@@ -203,24 +214,10 @@ __device__ __forceinline__ PairF ld_pix_pair(const void *base, unsigned elem)
     }
 }
 
-__device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx, float u, float v)
+// the sample point (y, x) itself; see lean_taps for how it is formed
+__device__ __forceinline__ LeanTaps lean_taps_at(const LeanGeom &g, double y, double x)
 {
     LeanTaps t;
-    if constexpr ((OFLK_ABLATE & 128) != 0) {   // the cell itself: no fp64 at all
-        t.inside = true;
-        t.off0 = ((unsigned)__mul24(min(gy, (int)g.Hm2), g.W) + (unsigned)min(gx, (int)g.Wm2)) * 4u + (u + v == 12345.0f ? 4u : 0u);
-        t.wy0 = t.wy1 = t.wx0 = t.wx1 = 0.0;
-        return t;
-    }
-    if constexpr ((OFLK_ABLATE & 8) != 0) {
-        const int yy = gy + (int)v, xx = gx + (int)u;
-        t.inside = (unsigned)yy < (unsigned)(int)g.Hm1 && (unsigned)xx < (unsigned)(int)g.Wm1;
-        t.off0 = t.inside ? ((unsigned)__mul24(yy, g.W) + (unsigned)xx) * 4u : 0u;
-        t.wy0 = t.wy1 = t.wx0 = t.wx1 = 0.0;
-        return t;
-    }
-    const double y = (double)gy + (double)v;   // int64 + float32 -> float64, as the reference
-    const double x = (double)gx + (double)u;
     // 0 <= y <= H-1 as ONE unsigned compare of the bit patterns: non-negative doubles order like
     // their bits, and a set sign bit (y < 0; y = -0.0 cannot come out of the sum above) or a NaN
     // reads as larger than any in-range value.  Two compares and one scalar AND, no branches.
@@ -237,6 +234,24 @@ __device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx,
     const unsigned cell = (unsigned)__mul24(y0, g.W) + (unsigned)x0;   // H, W < 2^24 (host check)
     t.off0 = t.inside ? cell * 4u : 0u;
     return t;
+}
+
+__device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx, float u, float v)
+{
+    const double y = (double)gy + (double)v;   // int64 + float32 -> float64, as the reference
+    const double x = (double)gx + (double)u;
+    return lean_taps_at(g, y, x);
+}
+
+// (double)n for 0 <= n < 2^31 with integer operations only: for a wave-uniform n they all run on the
+// scalar ALU and the result lives in an SGPR pair (int -> fp64 conversion only exists on the vector ALU,
+// which is the fused iteration kernel's scarce resource)
+__device__ __forceinline__ double uint_to_f64_bits(int n)
+{
+    const int e = 31 - __builtin_clz((unsigned)n | 1u);   // n = 0: e = 0, patched below
+    const unsigned long long bits = ((unsigned long long)(1023 + e) << 52) + ((unsigned long long)(unsigned)n << (52 - e)) -
+                                    (1ull << 52);
+    return __longlong_as_double((long long)(n ? bits : 0ull));
 }
 
 // NARROW = false: the caller guarantees W >= 2 (and skips the one-column form)
@@ -522,7 +537,11 @@ __device__ __forceinline__ void patch5_sums(LoadRow load_row, T (&out)[NY][2])
                 T hi = (R4[oy][x] + R0[oy + 1][x]) + (R0[oy + 1][x + 1] + R2[oy + 1][x]);
                 T res = lo + hi;
                 res = res + w[i][x + 4];           // a[24]
+#ifdef OFLK_X_NOZERO
+                out[oy][x] = res;
+#else
                 out[oy][x] = zero_of<T>() + res;   // np.sum starts from the identity 0
+#endif
                 pin(out[oy][x]);
             }
         }
@@ -747,7 +766,11 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     constexpr int AH = k5TY + 2 * R;                       // staging rows (y0-R ..)
     constexpr int AS = LkGeom<HW>::AS;                     // staging columns (x0-SX ..)
     constexpr int PH = k5TY + 2 * HW, PW = k5TX + 2 * HW;  // product tile at (y0-HW, x0-HW)
-    constexpr int NG = (PH * PW + 255) / 256;              // gradient pixels per thread
+    constexpr int NG = (PH * PW + 255) / 256;              // gradient pixels per thread (GRADS: linear cell index)
+    constexpr int RPW2 = (PH + 3) / 4;                     // stage 2: gradient rows per wave (lane = column)
+    constexpr int HC2 = 2 * HW;                            // halo columns of the gradient tile
+    constexpr int NHP2 = (HC2 * RPW2 + 63) / 64;           // halo cells per thread
+    constexpr int NGA = MODE == MODE_GRADS ? NG : RPW2 + NHP2;   // gradient cells a thread holds
     constexpr int NGRP = AH * k5GW;                        // groups of 4 staging cells
     constexpr int NV = (NGRP + 255) / 256;                 // groups per thread
     constexpr int GC = SX - HW;                            // staging column of gradient column 0
@@ -837,7 +860,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
 #endif
         OFLK_STAMP(0);   // [0] top of the tile
 
-        float gix[NG], giy[NG], git[NG];
+        float gix[NGA], giy[NGA], git[NGA];
         if (MODE == MODE_GRADS) {
             const float *__restrict__ gtp = a.aux + (size_t)b * plane;
 #pragma unroll
@@ -870,95 +893,108 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                 constexpr int rstart = decltype(rs)::value;
                 if (MODE == MODE_ITER) {
                     const float2 *__restrict__ fl_in = a.fl[sel] + (size_t)b * plane;
-                    // Per-cell path (adjacent lanes = adjacent cells, so the bilinear gathers of a
-                    // wave touch 2-3 cache lines per instruction).  All coalesced loads of the
-                    // thread's cells go out first, then the gathers in batches of BATCH cells.
-                    // Cell k of a thread is e = tid + 256 k over rows rstart .. AH-1; (row, col)
-                    // advance by (QS, RS) with carry at AW columns, which avoids a division per cell.
-                    constexpr int AW = k5TX + 2 * R;                 // cells per row (x0-R ..)
-                    constexpr int NE = (AH * AW + 255) / 256;        // cells per thread (full tile)
+                    // Lane = image column, wave = staging row.  Wave w fills rows rstart + w, rstart + w + 4, ... of
+                    // the 64 columns x0 .. x0+63 (lane l = column x0 + l): the row, its image row gy, (double)gy and
+                    // the row's base addresses are wave-uniform (scalar ALU), the column and (double)gx are fixed per
+                    // lane, the LDS address is a per-thread base plus a constant -- a cell costs the vector ALU its
+                    // fp64 sampling arithmetic and little else (a linear cell index over the 64+2R-wide tile cost ~60
+                    // integer / conversion instructions per thread and tile on top, at 4 SIMD cycles each).  The 2R
+                    // halo columns of a wave's rows are one more cell for 2R * (rows per wave) of its lanes, by the
+                    // generic per-cell arithmetic.  All coalesced loads of the thread's cells go out first, then the
+                    // bilinear gathers in batches of BATCH cells (adjacent lanes = adjacent cells: a wave's gather
+                    // touches 2-3 cache lines per instruction).
+                    constexpr int NR = AH - rstart;                  // staging rows to fill
+                    constexpr int RPW = (NR + 3) / 4;                // rows (= main cells) per wave / thread
+                    constexpr int HC = 2 * R;                        // halo cells per row
+                    constexpr int NHP = (HC * RPW + 63) / 64;        // halo cells per thread
+                    constexpr int NCELL = RPW + NHP;
                     constexpr int BATCH = HW == 2 ? OFLK_BATCH : 4;   // 3x3: one register too many at 5
-                    constexpr int QS = 256 / AW, RS = 256 % AW;      // row / column advance per 256 cells
                     constexpr int SC = SX - R;                       // staging column of cell column 0
-                    constexpr int ncells = (AH - rstart) * AW;
-                    const int r0 = rstart + tid / AW, c0 = tid % AW;
+                    const int lane = tid & 63;
+                    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
                     const int Hm1 = H - 1, Wm1 = W - 1;
                     const LeanGeom lg = lean_geom(H, W);
-                    float p[NE], q[NE], uu[NE], vv[NE];
-                    {
-                        int r = r0, c = c0;
+                    const int gxm = min(x0 + lane, Wm1);             // "symm" ring; farther cells are never used
+                    const double gxd = (double)gxm;
+                    const unsigned gx_pix = (unsigned)gxm * (unsigned)sizeof(PIX), gx_fl = (unsigned)gxm * 8u;   // byte offsets in a row
+                    // staging row of main cell k (wave-uniform); the last row group may run past the tile: those
+                    // waves redo the last row (same values to the same LDS cells)
+                    auto main_row = [&](int k) { return (rstart + 4 * k + 3 < AH) ? rstart + wv + 4 * k : min(rstart + wv + 4 * k, AH - 1); };
+                    // halo cell h of the thread: staging row and cell column (0 .. R-1, 64+R .. 64+2R-1)
+                    auto halo_pos = [&](int h, int &rr, int &c) {
+                        const int idx = min(lane + 64 * h, HC * RPW - 1);
+                        const int j = idx / HC, hc = idx - j * HC;
+                        rr = min(rstart + wv + 4 * j, AH - 1);
+                        c = hc < R ? hc : hc + 64;
+                    };
+                    float p[NCELL], q[NCELL], uu[NCELL], vv[NCELL];
     #pragma unroll
-                        for (int k = 0; k < NE; k++) {
-                            if (k * 256 < ncells) {  // uniform: cell k exists for some thread
-                                const int rr = (k + 1) * 256 <= ncells ? r : min(r, AH - 1);   // only the last k runs past the tile
-                                int gy = clamp0(y0 - R + rr, Hm1);  // "symm" ring; farther cells are never used
-                                int gx = clamp0(x0 - R + c, Wm1);
-                                const unsigned ie = (unsigned)__mul24(gy, W) + (unsigned)gx;
-                                p[k] = ld_pix<PIX>(prev, ie);
-                                if constexpr ((OFLK_ABLATE & 1024) != 0) {
-                                    uu[k] = vv[k] = 0.0f;
-                                } else {
-                                    const float2 f = ld_off<float2>(fl_in, ie * 8u);
-                                    uu[k] = f.x;
-                                    vv[k] = f.y;
-                                }
-                                c += RS; r += QS;
-                                if (c >= AW) { c -= AW; r += 1; }
-                            }
+                    for (int k = 0; k < NCELL; k++) {
+                        float2 f;
+                        if (k < RPW) {
+                            // scalar row base + the lane's fixed column offset: no vector address arithmetic
+                            const unsigned rowe = (unsigned)(min(max(y0 - R + main_row(k), 0), Hm1) * W);
+                            p[k] = (float)ld_off<PIX>(scalar_ptr(prev + rowe), gx_pix);
+                            f = ld_off<float2>(scalar_ptr(fl_in + rowe), gx_fl);
+                        } else {
+                            int rr, c;
+                            halo_pos(k - RPW, rr, c);
+                            const int gy = clamp0(y0 - R + rr, Hm1), gx = clamp0(x0 - R + c, Wm1);
+                            const unsigned ie = (unsigned)__mul24(gy, W) + (unsigned)gx;
+                            p[k] = ld_pix<PIX>(prev, ie);
+                            f = ld_off<float2>(fl_in, ie * 8u);
                         }
+                        uu[k] = f.x;
+                        vv[k] = f.y;
                     }
                     OFLK_STAMP(1);   // [1] carry -> LDS, addresses, issue of the coalesced loads (prev, u, v)
-                    {
-                        int r = r0, c = c0;
     #pragma unroll
-                        for (int k0 = 0; k0 < NE; k0 += BATCH) {
-                            if (k0 * 256 < ncells) {
-                                LeanTaps tp[BATCH];
-                                PairF pr0[BATCH], pr1[BATCH];
+                    for (int k0 = 0; k0 < NCELL; k0 += BATCH) {
+                        LeanTaps tp[BATCH];
+                        PairF pr0[BATCH], pr1[BATCH];
     #pragma unroll
-                                for (int j = 0; j < BATCH; j++) {
-                                    if (k0 + j < NE && (k0 + j) * 256 < ncells) {
-                                        const int rr = (k0 + j + 1) * 256 <= ncells ? r : min(r, AH - 1);
-                                        int gy = clamp0(y0 - R + rr, Hm1);
-                                        int gx = clamp0(x0 - R + c, Wm1);
-                                        tp[j] = lean_taps(lg, gy, gx, uu[k0 + j], vv[k0 + j]);  // lucas_kanade_pyramidal.py:88-95
-                                        // two 8-byte gathers per cell (the x pair of each tap row)
-                                        if constexpr ((OFLK_ABLATE & 256) != 0) {
-                                            pr0[j] = PairF{p[k0 + j], p[k0 + j]};
-                                            pr1[j] = pr0[j];
-                                        } else {
-                                            lean_load<false, PIX>(lg, curr, tp[j], pr0[j], pr1[j]);
-                                        }
-                                        c += RS; r += QS;
-                                        if (c >= AW) { c -= AW; r += 1; }
-                                    }
+                        for (int j = 0; j < BATCH; j++) {
+                            const int k = k0 + j;
+                            if (k < NCELL) {
+                                if (k < RPW) {
+                                    const int gy = min(max(y0 - R + main_row(k), 0), Hm1);
+                                    // int64 + float32 -> float64, as the reference (lucas_kanade_pyramidal.py:88-95)
+                                    const double y = uint_to_f64_bits(gy) + (double)vv[k];
+                                    const double x = gxd + (double)uu[k];
+                                    tp[j] = lean_taps_at(lg, y, x);
+                                } else {
+                                    int rr, c;
+                                    halo_pos(k - RPW, rr, c);
+                                    const int gy = clamp0(y0 - R + rr, Hm1), gx = clamp0(x0 - R + c, Wm1);
+                                    tp[j] = lean_taps(lg, gy, gx, uu[k], vv[k]);
                                 }
-                                OFLK_STAMP(k0 == 0 ? 2 : 4);   // [2]/[4] wait for u, v; taps; gathers issued
-    #pragma unroll
-                                for (int j = 0; j < BATCH; j++)
-                                    if (k0 + j < NE && (k0 + j) * 256 < ncells) {
-                                        q[k0 + j] = lean_finish(tp[j], pr0[j], pr1[j]);
-                                        pin(q[k0 + j]);  // finished here, not sunk to its use after the last batch
-                                    }
-                                __builtin_amdgcn_sched_barrier(0);  // one batch of taps in flight at a time
-                                OFLK_STAMP(k0 == 0 ? 3 : 5);   // [3]/[5] wait for the gathers; fp64 tap sums
+                                // two 8-byte gathers per cell (the x pair of each tap row)
+                                lean_load<false, PIX>(lg, curr, tp[j], pr0[j], pr1[j]);
                             }
                         }
+                        OFLK_STAMP(k0 == 0 ? 2 : 4);   // [2]/[4] wait for u, v; taps; gathers issued
+    #pragma unroll
+                        for (int j = 0; j < BATCH; j++)
+                            if (k0 + j < NCELL) {
+                                q[k0 + j] = lean_finish(tp[j], pr0[j], pr1[j]);
+                                pin(q[k0 + j]);  // finished here, not sunk to its use after the last batch
+                            }
+                        __builtin_amdgcn_sched_barrier(0);  // one batch of taps in flight at a time
+                        OFLK_STAMP(k0 == 0 ? 3 : 5);   // [3]/[5] wait for the gathers; fp64 tap sums
                     }
-                    {
-                        int r = r0, c = c0;
     #pragma unroll
-                        for (int k = 0; k < NE; k++) {
-                            if (k * 256 < ncells) {
-                                if ((k + 1) * 256 <= ncells || r < AH) {   // cell k exists for every thread unless it is the last
-                                    float sum = p[k] + q[k];
-                                    s_avg[r * AS + c + SC] = sum * 0.5f;
-                                    s_it[r * AS + c + SC] = p[k] - q[k];
-                                }
-                                c += RS; r += QS;
-                                if (c >= AW) { c -= AW; r += 1; }
-                            }
+                    for (int k = 0; k < NCELL; k++) {
+                        int o;
+                        if (k < RPW) {
+                            o = main_row(k) * AS + SX + lane;
+                        } else {
+                            int rr, c;
+                            halo_pos(k - RPW, rr, c);
+                            o = rr * AS + c + SC;
                         }
+                        const float sum = p[k] + q[k];
+                        s_avg[o] = sum * 0.5f;
+                        s_it[o] = p[k] - q[k];
                     }
                 } else {
                     // SINGLE: groups of four cells over staging rows rstart .. AH-1
@@ -1024,22 +1060,16 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             __syncthreads();
             OFLK_STAMP(7);    // [7] barrier 1
             // ---- stage 2: Sobel/8 in convolve2d's tap order; gradients stay in registers
-#pragma unroll
-            for (int k = 0; k < NG; k++) {
-                int e = tid + k * 256;
-                if (e >= PH * PW) e = PH * PW - 1;  // tail threads recompute the last cell
-                int r = e / PW, c = e - r * PW;
-                // gradient cell (r, c) = image (y0-HW+r, x0-HW+c) = staging cell (r+1, c+GC)
-                const float *ap = &s_avg[(r + 1) * AS + (c + GC)];
-                float a_mm = ap[-AS - 1], a_m0 = ap[-AS], a_mp = ap[-AS + 1];
-                float a_0m = ap[-1], a_0p = ap[1];
-                float a_pm = ap[AS - 1], a_p0 = ap[AS], a_pp = ap[AS + 1];
-                float ix = a_pp * -0.125f;
-                float iy = a_pp * -0.125f;
-                if constexpr ((OFLK_ABLATE & 16) != 0) {
-                    ix = a_0p + a_0m;
-                    iy = a_p0 + a_m0;
-                } else {
+            // Lane = column, wave = RPW2 consecutive rows of the PH x PW gradient tile (the last wave's rows
+            // overlap its neighbour's when PH is not a multiple of 4: same values twice).  A wave walks down its
+            // rows with the three frame-average rows of the stencil in registers, so a cell reads three new
+            // averages and its It, and every LDS address is a per-thread base plus a constant.  The 2 HW halo
+            // columns are one more cell for 2 HW * RPW2 of a wave's lanes.
+            // gradient cell (r, c) = image (y0-HW+r, x0-HW+c) = staging cell (r+1, c+GC)
+            auto sobel = [](float a_mm, float a_m0, float a_mp, float a_0m, float a_0p, float a_pm, float a_p0, float a_pp,
+                            float &ix, float &iy) {
+                ix = a_pp * -0.125f;
+                iy = a_pp * -0.125f;
                 ix = fmaf(a_pm, 0.125f, ix);
                 ix = fmaf(a_0p, -0.25f, ix);
                 ix = fmaf(a_0m, 0.25f, ix);
@@ -1050,10 +1080,32 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                 iy = fmaf(a_mp, 0.125f, iy);
                 iy = fmaf(a_m0, 0.25f, iy);
                 iy = fmaf(a_mm, 0.125f, iy);
+            };
+            {
+                const int lane = tid & 63;
+                const int rbase = min(__builtin_amdgcn_readfirstlane(tid >> 6) * RPW2, PH - RPW2);
+                const float *ap = &s_avg[rbase * AS + SX + lane];   // staging row rbase = row "minus" of gradient row rbase
+                const float *tp = &s_it[(rbase + 1) * AS + SX + lane];
+                float m_m = ap[-1], m_0 = ap[0], m_p = ap[1];
+                float z_m = ap[AS - 1], z_0 = ap[AS], z_p = ap[AS + 1];
+#pragma unroll
+                for (int k = 0; k < RPW2; k++) {
+                    const float p_m = ap[(k + 2) * AS - 1], p_0 = ap[(k + 2) * AS], p_p = ap[(k + 2) * AS + 1];
+                    sobel(m_m, m_0, m_p, z_m, z_p, p_m, p_0, p_p, gix[k], giy[k]);
+                    git[k] = tp[k * AS];
+                    m_m = z_m; m_0 = z_0; m_p = z_p;
+                    z_m = p_m; z_0 = p_0; z_p = p_p;
                 }
-                gix[k] = ix;
-                giy[k] = iy;
-                git[k] = s_it[(r + 1) * AS + (c + GC)];
+#pragma unroll
+                for (int h = 0; h < NHP2; h++) {
+                    const int idx = min(lane + 64 * h, HC2 * RPW2 - 1);
+                    const int j = idx / HC2, hc = idx - j * HC2;
+                    const int r = rbase + j, c = hc < HW ? hc : hc + 64;
+                    const float *hp = &s_avg[(r + 1) * AS + (c + GC)];
+                    sobel(hp[-AS - 1], hp[-AS], hp[-AS + 1], hp[-1], hp[1], hp[AS - 1], hp[AS], hp[AS + 1], gix[RPW2 + h],
+                          giy[RPW2 + h]);
+                    git[RPW2 + h] = s_it[(r + 1) * AS + (c + GC)];
+                }
             }
             if (CHAIN && it + 1 < ntile) {
                 // staging rows TY .. AH-1 are the next tile's rows 0 .. 2R-1
@@ -1071,10 +1123,30 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             OFLK_STAMP(9);    // [9] barrier 2
         }
         // ---- products into the interleaved planes --------------------------------
+        if (MODE == MODE_GRADS) {
 #pragma unroll
-        for (int k = 0; k < NG; k++) {
-            int e = tid + k * 256;
-            if ((k + 1) * 256 <= PH * PW || e < PH * PW) {   // only the last k is partial
+            for (int k = 0; k < NG; k++) {
+                int e = tid + k * 256;
+                if ((k + 1) * 256 <= PH * PW || e < PH * PW) {   // only the last k is partial
+                    float ix = gix[k], iy = giy[k], itv = git[k];
+                    s_pa[e] = make_float2(ix * ix, iy * iy);
+                    s_pb[e] = make_float2(ix * iy, ix * itv);
+                    s_pc[e] = iy * itv;
+                }
+            }
+        } else {
+            const int lane = tid & 63;
+            const int rbase = min(__builtin_amdgcn_readfirstlane(tid >> 6) * RPW2, PH - RPW2);
+#pragma unroll
+            for (int k = 0; k < RPW2 + NHP2; k++) {
+                int e;
+                if (k < RPW2) {
+                    e = (rbase + k) * PW + HW + lane;
+                } else {
+                    const int idx = min(lane + 64 * (k - RPW2), HC2 * RPW2 - 1);
+                    const int j = idx / HC2, hc = idx - j * HC2;
+                    e = (rbase + j) * PW + (hc < HW ? hc : hc + 64);
+                }
                 float ix = gix[k], iy = giy[k], itv = git[k];
                 s_pa[e] = make_float2(ix * ix, iy * iy);
                 s_pb[e] = make_float2(ix * iy, ix * itv);
