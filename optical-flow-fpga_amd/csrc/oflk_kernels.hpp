@@ -36,6 +36,12 @@
 #ifndef OFLK_ABLATE
 #define OFLK_ABLATE 0
 #endif
+#ifndef OFLK_X_CONSEC
+#define OFLK_X_CONSEC 0
+#endif
+#ifndef OFLK_X_VCVT
+#define OFLK_X_VCVT 0
+#endif
 
 namespace oflk {
 
@@ -236,6 +242,30 @@ __device__ __forceinline__ LeanTaps lean_taps_at(const LeanGeom &g, double y, do
     return t;
 }
 
+// The same sample with the weights formed as late as possible: between the gathers' issue and their use a cell
+// holds its two fractions (4 registers) instead of four weights (8), so that all cells of a tile can have their
+// gathers in flight together.  Same operations in the same order as lean_taps_at + lean_finish.
+struct LeanFrac {
+    unsigned off0;
+    double ry, rx;
+    bool inside;
+};
+
+__device__ __forceinline__ LeanFrac lean_frac_at(const LeanGeom &g, double y, double x)
+{
+    LeanFrac t;
+    const int in_y = (unsigned long long)__double_as_longlong(y) <= (unsigned long long)__double_as_longlong(g.Hm1);
+    const int in_x = (unsigned long long)__double_as_longlong(x) <= (unsigned long long)__double_as_longlong(g.Wm1);
+    t.inside = (in_y & in_x) != 0;
+    const double fy = fmin(floor(y), g.Hm2), fx = fmin(floor(x), g.Wm2);
+    t.ry = y - fy;
+    t.rx = x - fx;
+    const int y0 = (int)fy, x0 = (int)fx;      // in range whenever `inside`
+    const unsigned cell = (unsigned)__mul24(y0, g.W) + (unsigned)x0;   // H, W < 2^24 (host check)
+    t.off0 = t.inside ? cell * 4u : 0u;
+    return t;
+}
+
 __device__ __forceinline__ LeanTaps lean_taps(const LeanGeom &g, int gy, int gx, float u, float v)
 {
     const double y = (double)gy + (double)v;   // int64 + float32 -> float64, as the reference
@@ -255,8 +285,8 @@ __device__ __forceinline__ double uint_to_f64_bits(int n)
 }
 
 // NARROW = false: the caller guarantees W >= 2 (and skips the one-column form)
-template <bool NARROW, class PIX = float>
-__device__ __forceinline__ void lean_load(const LeanGeom &g, const void *__restrict__ img, const LeanTaps &t,
+template <bool NARROW, class PIX = float, class TAPS = LeanTaps>
+__device__ __forceinline__ void lean_load(const LeanGeom &g, const void *__restrict__ img, const TAPS &t,
                                           PairF &r0, PairF &r1)
 {
     // off0 / rowstep are byte offsets of float32 cells: element offsets are a quarter of them
@@ -280,6 +310,18 @@ __device__ __forceinline__ float lean_finish(const LeanTaps &t, PairF r0, PairF 
     c = (double)r0.b; c = c * t.wy0; c = c * t.wx1; acc = acc + c;
     c = (double)r1.a; c = c * t.wy1; c = c * t.wx0; acc = acc + c;
     c = (double)r1.b; c = c * t.wy1; c = c * t.wx1; acc = acc + c;
+    return t.inside ? (float)acc : 0.0f;
+}
+
+__device__ __forceinline__ float lean_finish(const LeanFrac &t, PairF r0, PairF r1)
+{
+    const double wy0 = 1.0 - t.ry, wx0 = 1.0 - t.rx;
+    const double wy1 = 1.0 - wy0, wx1 = 1.0 - wx0;
+    double acc, c;
+    c = (double)r0.a; c = c * wy0; acc = c * wx0;
+    c = (double)r0.b; c = c * wy0; c = c * wx1; acc = acc + c;
+    c = (double)r1.a; c = c * wy1; c = c * wx0; acc = acc + c;
+    c = (double)r1.b; c = c * wy1; c = c * wx1; acc = acc + c;
     return t.inside ? (float)acc : 0.0f;
 }
 
@@ -392,7 +434,7 @@ struct LkArgs {
 #define OFLK_NY 3      // output rows per thread: tile = 64 x 8*NY
 #endif
 #ifndef OFLK_BATCH
-#define OFLK_BATCH 5   // warp cells whose gathers are in flight together (ITER stage 1, 5x5 window)
+#define OFLK_BATCH 7   // warp cells whose gathers are in flight together (ITER stage 1, 5x5 window)
 #endif
 // XCD-aware tile order (speed only, never correctness).  Workgroups of a 1-D grid are
 // dealt round-robin over the 8 XCDs (ids i and i+8 share an XCD, each with its own L2).
@@ -756,8 +798,53 @@ constexpr bool kLkChain = HW <= 2 && MODE != MODE_GRADS;
 #define OFLK_STAMP_OCC
 #endif
 
+
+// sensitivity probes (tools only): OFLK_X_PROBE = (site << 8) | kind, site 1 = stage 1 after the coalesced loads are issued,
+// 3 = stage 3 after the window sums; kind 1 = 96 v_add_f32, 2 = 96 v_add_f64, 3 = 96 s_mov_b32, 4 = 24 ds_read_b32
+#ifndef OFLK_X_PROBE
+#define OFLK_X_PROBE 0
+#endif
+template <int SITE>
+__device__ __forceinline__ void probe(const float *lds)
+{
+    if constexpr ((OFLK_X_PROBE >> 8) == SITE) {
+        constexpr int KIND = OFLK_X_PROBE & 255;
+        if constexpr (KIND == 1) {
+            float r[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                asm volatile("v_add_f32 %0, %0, %0\nv_add_f32 %1, %1, %1\nv_add_f32 %2, %2, %2\nv_add_f32 %3, %3, %3\n"
+                             "v_add_f32 %4, %4, %4\nv_add_f32 %5, %5, %5\nv_add_f32 %6, %6, %6\nv_add_f32 %7, %7, %7\n"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+        } else if constexpr (KIND == 2) {
+            double r[4] = {1, 2, 3, 4};
+#pragma unroll
+            for (int i = 0; i < 24; i++)
+                asm volatile("v_add_f64 %0, %0, %0\nv_add_f64 %1, %1, %1\nv_add_f64 %2, %2, %2\nv_add_f64 %3, %3, %3\n"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+        } else if constexpr (KIND == 3) {
+            int r[4] = {1, 2, 3, 4};
+#pragma unroll
+            for (int i = 0; i < 24; i++)
+                asm volatile("s_mov_b32 %0, %1\ns_mov_b32 %1, %2\ns_mov_b32 %2, %3\ns_mov_b32 %3, %0\n"
+                             : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]));
+        } else if constexpr (KIND == 4) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 24; i++) acc += *(const volatile float *)(lds + threadIdx.x + 64 * i);
+            asm volatile("" ::"v"(acc));
+        }
+    }
+}
+
+// four waves per SIMD (<= 128 VGPRs) for the 5x5 iteration kernel: the allocator lands one register above it otherwise
+#ifdef OFLK_X_PF
+#define OFLK_LKW_OCC __attribute__((amdgpu_waves_per_eu(HW == 2 && MODE == MODE_ITER ? 4 : 1)))
+#else
+#define OFLK_LKW_OCC
+#endif
 template <int HW, int MODE, bool VEC, class PIX = float>
-__global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
+__global__ __launch_bounds__(256) OFLK_LKW_OCC void k_lkw(LkArgs a)
 {
     static_assert(MODE != MODE_GRADS || sizeof(PIX) == 4, "gradient planes are float32");
     static_assert(HW >= 1 && HW <= 5, "windows up to 11x11 (NumPy's single pairwise block)");
@@ -780,6 +867,10 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     // one LDS block: [PA float2 | PB float2 | PC float]; avg and It alias its start
     __shared__ __attribute__((aligned(16))) float s_mem[PH * PW * 5];
     __shared__ double s_red[2][4];
+#ifdef OFLK_X_PAD
+    __shared__ float s_pad[OFLK_X_PAD];   // experiment: LDS footprint of a flow ring (3 blocks per CU)
+    if (a.H == -12345) s_pad[threadIdx.x] = 1.0f;
+#endif
     float2 *s_pa = reinterpret_cast<float2 *>(s_mem);
     float2 *s_pb = reinterpret_cast<float2 *>(s_mem + PH * PW * 2);
     float *s_pc = s_mem + PH * PW * 4;
@@ -838,6 +929,67 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
     const int x0 = tile_x * k5TX;
     float carry_a[NC], carry_i[NC];
     double blk_u = 0.0, blk_v = 0.0;   // thread 0: |d| sums of the block's tiles
+
+    // ---- ITER stage 1 geometry: lane = image column, wave = staging row -------------------------------------
+    // Wave w fills rows rs + w, rs + w + 4, ... of the 64 columns x0 .. x0+63 (lane l = column x0 + l): the row, its
+    // image row gy, (double)gy and the row's base addresses are wave-uniform (scalar ALU), the column and (double)gx
+    // are fixed per lane, the LDS address is a per-thread base plus a constant -- a cell costs the vector ALU its fp64
+    // sampling arithmetic and little else.  The 2R halo columns of a wave's rows are one more cell for
+    // 2R * (rows per wave) of its lanes, by the generic per-cell arithmetic.
+    // A tile's coalesced loads (prev, {u, v}) of a CONTINUING tile (rows 2R ..) are issued by the tile before it,
+    // between its window sums and its solve (lk_prefetch below): they travel while that tile divides and stores, so
+    // a tile starts with its flow in registers and the chain of dependent round trips per tile is one gather long.
+    constexpr int ST1_HC = 2 * R;                                     // halo cells per staging row
+    constexpr int ST1_RPW_C = (AH - 2 * R + 3) / 4;                   // rows per wave, continuing tile
+    constexpr int ST1_NCELL_C = ST1_RPW_C + (ST1_HC * ST1_RPW_C + 63) / 64;   // cells per thread, continuing tile
+#ifdef OFLK_X_PF
+    constexpr bool PREFETCH = CHAIN && MODE == MODE_ITER;
+#else
+    constexpr bool PREFETCH = false;
+#endif
+    float pre_p[PREFETCH ? ST1_NCELL_C : 1];
+    float2 pre_f[PREFETCH ? ST1_NCELL_C : 1];
+    // staging row of main cell k of wave wv (wave-uniform); the last row group may run past the tile: those waves
+    // redo the last row (same values to the same LDS cells)
+    auto st1_main_row = [](auto rs, int wv, int k) {
+        constexpr int rstart = decltype(rs)::value;
+        return (rstart + 4 * k + 3 < AH) ? rstart + wv + 4 * k : min(rstart + wv + 4 * k, AH - 1);
+    };
+    // halo cell h of a thread: staging row and cell column (0 .. R-1, 64+R .. 64+2R-1)
+    auto st1_halo_pos = [](auto rs, int wv, int lane, int h, int &rr, int &c) {
+        constexpr int rstart = decltype(rs)::value;
+        constexpr int RPW = (AH - rstart + 3) / 4;
+        const int idx = min(lane + 64 * h, ST1_HC * RPW - 1);
+        const int j = idx / ST1_HC, hc = idx - j * ST1_HC;
+        rr = min(rstart + wv + 4 * j, AH - 1);
+        c = hc < R ? hc : hc + 64;
+    };
+    // all coalesced loads of a thread's stage-1 cells for the tile at image row y0t
+    auto st1_loads = [&](auto rs, int tid, int y0t, auto &P, auto &F) {
+        constexpr int rstart = decltype(rs)::value;
+        constexpr int RPW = (AH - rstart + 3) / 4, NHP = (ST1_HC * RPW + 63) / 64;
+        const float2 *__restrict__ fl_in = a.fl[sel] + (size_t)b * plane;
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int Hm1 = H - 1, Wm1 = W - 1;
+        const int gxm = min(x0 + lane, Wm1);             // "symm" ring; farther cells are never used
+        const unsigned gx_pix = (unsigned)gxm * (unsigned)sizeof(PIX), gx_fl = (unsigned)gxm * 8u;   // byte offsets in a row
+#pragma unroll
+        for (int k = 0; k < RPW + NHP; k++) {
+            if (k < RPW) {
+                // scalar row base + the lane's fixed column offset: no vector address arithmetic
+                const unsigned rowe = (unsigned)(min(max(y0t - R + st1_main_row(rs, wv, k), 0), Hm1) * W);
+                P[k] = (float)ld_off<PIX>(scalar_ptr(prev + rowe), gx_pix);
+                F[k] = ld_off<float2>(scalar_ptr(fl_in + rowe), gx_fl);
+            } else {
+                int rr, c;
+                st1_halo_pos(rs, wv, lane, k - RPW, rr, c);
+                const int gy = clamp0(y0t - R + rr, Hm1), gx = clamp0(x0 - R + c, Wm1);
+                const unsigned ie = (unsigned)__mul24(gy, W) + (unsigned)gx;
+                P[k] = ld_pix<PIX>(prev, ie);
+                F[k] = ld_off<float2>(fl_in, ie * 8u);
+            }
+        }
+    };
 #ifdef OFLK_STAMPS
     __shared__ unsigned s_st[4][8][16];
     const int st_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -892,87 +1044,82 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             auto stage1 = [&](auto rs) {
                 constexpr int rstart = decltype(rs)::value;
                 if (MODE == MODE_ITER) {
-                    const float2 *__restrict__ fl_in = a.fl[sel] + (size_t)b * plane;
-                    // Lane = image column, wave = staging row.  Wave w fills rows rstart + w, rstart + w + 4, ... of
-                    // the 64 columns x0 .. x0+63 (lane l = column x0 + l): the row, its image row gy, (double)gy and
-                    // the row's base addresses are wave-uniform (scalar ALU), the column and (double)gx are fixed per
-                    // lane, the LDS address is a per-thread base plus a constant -- a cell costs the vector ALU its
-                    // fp64 sampling arithmetic and little else (a linear cell index over the 64+2R-wide tile cost ~60
-                    // integer / conversion instructions per thread and tile on top, at 4 SIMD cycles each).  The 2R
-                    // halo columns of a wave's rows are one more cell for 2R * (rows per wave) of its lanes, by the
-                    // generic per-cell arithmetic.  All coalesced loads of the thread's cells go out first, then the
-                    // bilinear gathers in batches of BATCH cells (adjacent lanes = adjacent cells: a wave's gather
-                    // touches 2-3 cache lines per instruction).
+                    // (geometry: see st1_loads above)  The bilinear gathers of all the thread's cells are in flight
+                    // together when the registers allow it (a continuing tile of the 5x5 window: 7 cells); adjacent
+                    // lanes = adjacent cells, so a wave's gather touches 2-3 cache lines per instruction.
                     constexpr int NR = AH - rstart;                  // staging rows to fill
                     constexpr int RPW = (NR + 3) / 4;                // rows (= main cells) per wave / thread
-                    constexpr int HC = 2 * R;                        // halo cells per row
-                    constexpr int NHP = (HC * RPW + 63) / 64;        // halo cells per thread
+                    constexpr int NHP = (ST1_HC * RPW + 63) / 64;    // halo cells per thread
                     constexpr int NCELL = RPW + NHP;
-                    constexpr int BATCH = HW == 2 ? OFLK_BATCH : 4;   // 3x3: one register too many at 5
+                    constexpr int BATCH = HW != 2 ? 4 : (NCELL <= OFLK_BATCH ? NCELL : (NCELL + 1) / 2);
                     constexpr int SC = SX - R;                       // staging column of cell column 0
                     const int lane = tid & 63;
                     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
                     const int Hm1 = H - 1, Wm1 = W - 1;
                     const LeanGeom lg = lean_geom(H, W);
-                    const int gxm = min(x0 + lane, Wm1);             // "symm" ring; farther cells are never used
+                    const int gxm = min(x0 + lane, Wm1);
                     const double gxd = (double)gxm;
-                    const unsigned gx_pix = (unsigned)gxm * (unsigned)sizeof(PIX), gx_fl = (unsigned)gxm * 8u;   // byte offsets in a row
-                    // staging row of main cell k (wave-uniform); the last row group may run past the tile: those
-                    // waves redo the last row (same values to the same LDS cells)
-                    auto main_row = [&](int k) { return (rstart + 4 * k + 3 < AH) ? rstart + wv + 4 * k : min(rstart + wv + 4 * k, AH - 1); };
-                    // halo cell h of the thread: staging row and cell column (0 .. R-1, 64+R .. 64+2R-1)
-                    auto halo_pos = [&](int h, int &rr, int &c) {
-                        const int idx = min(lane + 64 * h, HC * RPW - 1);
-                        const int j = idx / HC, hc = idx - j * HC;
-                        rr = min(rstart + wv + 4 * j, AH - 1);
-                        c = hc < R ? hc : hc + 64;
-                    };
-                    float p[NCELL], q[NCELL], uu[NCELL], vv[NCELL];
-    #pragma unroll
-                    for (int k = 0; k < NCELL; k++) {
-                        float2 f;
-                        if (k < RPW) {
-                            // scalar row base + the lane's fixed column offset: no vector address arithmetic
-                            const unsigned rowe = (unsigned)(min(max(y0 - R + main_row(k), 0), Hm1) * W);
-                            p[k] = (float)ld_off<PIX>(scalar_ptr(prev + rowe), gx_pix);
-                            f = ld_off<float2>(scalar_ptr(fl_in + rowe), gx_fl);
-                        } else {
-                            int rr, c;
-                            halo_pos(k - RPW, rr, c);
-                            const int gy = clamp0(y0 - R + rr, Hm1), gx = clamp0(x0 - R + c, Wm1);
-                            const unsigned ie = (unsigned)__mul24(gy, W) + (unsigned)gx;
-                            p[k] = ld_pix<PIX>(prev, ie);
-                            f = ld_off<float2>(fl_in, ie * 8u);
+                    float p[NCELL], q[NCELL];
+                    float2 f[NCELL];
+                    if constexpr (PREFETCH && rstart != 0) {
+                        static_assert(NCELL == ST1_NCELL_C, "the prefetched cells are a continuing tile's");
+#pragma unroll
+                        for (int k = 0; k < NCELL; k++) {
+                            p[k] = pre_p[k];
+                            f[k] = pre_f[k];
                         }
-                        uu[k] = f.x;
-                        vv[k] = f.y;
+                    } else {
+                        st1_loads(rs, tid, y0, p, f);
                     }
                     OFLK_STAMP(1);   // [1] carry -> LDS, addresses, issue of the coalesced loads (prev, u, v)
+                    probe<1>(s_mem);
     #pragma unroll
                     for (int k0 = 0; k0 < NCELL; k0 += BATCH) {
-                        LeanTaps tp[BATCH];
+                        LeanFrac tp[BATCH];
                         PairF pr0[BATCH], pr1[BATCH];
     #pragma unroll
                         for (int j = 0; j < BATCH; j++) {
                             const int k = k0 + j;
                             if (k < NCELL) {
+                                double y, x;   // int64 + float32 -> float64, as the reference (lucas_kanade_pyramidal.py:88-95)
                                 if (k < RPW) {
-                                    const int gy = min(max(y0 - R + main_row(k), 0), Hm1);
-                                    // int64 + float32 -> float64, as the reference (lucas_kanade_pyramidal.py:88-95)
-                                    const double y = uint_to_f64_bits(gy) + (double)vv[k];
-                                    const double x = gxd + (double)uu[k];
-                                    tp[j] = lean_taps_at(lg, y, x);
+                                    const int gy = min(max(y0 - R + st1_main_row(rs, wv, k), 0), Hm1);
+#if OFLK_X_VCVT
+                                    y = (double)gy + (double)f[k].y;
+#else
+                                    y = uint_to_f64_bits(gy) + (double)f[k].y;
+#endif
+                                    x = gxd + (double)f[k].x;
                                 } else {
                                     int rr, c;
-                                    halo_pos(k - RPW, rr, c);
-                                    const int gy = clamp0(y0 - R + rr, Hm1), gx = clamp0(x0 - R + c, Wm1);
-                                    tp[j] = lean_taps(lg, gy, gx, uu[k], vv[k]);
+                                    st1_halo_pos(rs, wv, lane, k - RPW, rr, c);
+                                    y = (double)clamp0(y0 - R + rr, Hm1) + (double)f[k].y;
+                                    x = (double)clamp0(x0 - R + c, Wm1) + (double)f[k].x;
                                 }
+                                tp[j] = lean_frac_at(lg, y, x);
                                 // two 8-byte gathers per cell (the x pair of each tap row)
+#ifdef OFLK_X_HALFG
+                                if ((k & 1) && k < RPW) { pr0[j] = pr0[j - 1]; pr1[j] = pr1[j - 1]; } else   // timing experiment (wrong results)
+#endif
                                 lean_load<false, PIX>(lg, curr, tp[j], pr0[j], pr1[j]);
                             }
                         }
                         OFLK_STAMP(k0 == 0 ? 2 : 4);   // [2]/[4] wait for u, v; taps; gathers issued
+                        if constexpr ((OFLK_X_PROBE >> 8) == 2) {
+                            if (k0 == 0) {
+                                constexpr int KIND = OFLK_X_PROBE & 255;
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    if constexpr (KIND == 5) {   // four more 8-byte gathers next to the thread's first cell
+                                        PairF x_ = ld_off<PairF>(curr, tp[0].off0 + 8u * (unsigned)e + 1024u);
+                                        asm volatile("" ::"v"(x_.a), "v"(x_.b));
+                                    } else if constexpr (KIND == 6) {   // four more coalesced 4-byte loads
+                                        float x_ = ld_off<float>(curr, tp[0].off0 + 7680u * (unsigned)(e + 1));
+                                        asm volatile("" ::"v"(x_));
+                                    }
+                                }
+                            }
+                        }
     #pragma unroll
                         for (int j = 0; j < BATCH; j++)
                             if (k0 + j < NCELL) {
@@ -986,10 +1133,10 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
                     for (int k = 0; k < NCELL; k++) {
                         int o;
                         if (k < RPW) {
-                            o = main_row(k) * AS + SX + lane;
+                            o = st1_main_row(rs, wv, k) * AS + SX + lane;
                         } else {
                             int rr, c;
-                            halo_pos(k - RPW, rr, c);
+                            st1_halo_pos(rs, wv, lane, k - RPW, rr, c);
                             o = rr * AS + c + SC;
                         }
                         const float sum = p[k] + q[k];
@@ -1206,6 +1353,14 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             const float2 *bb = &s_pb[(NY * ty) * PW + 2 * tx];
             patch5_sums<Sum2, NY>([&](int i, Sum2 (&row)[6]) { load_f2(bb + i * PW, row); }, sB);
             if constexpr (PRELOAD) preload();
+            if constexpr (PREFETCH) {
+                // The next tile's coalesced loads, behind the epilogue's own (loads return in order): they travel while
+                // this tile sums its last plane, divides and stores.  Issued for the tile past the segment's last one
+                // too (row indices are clamped into the image: the loads are valid, their values unused) -- with the
+                // same loads on every path the compiler counts them exactly and the epilogue waits for its own loads
+                // only (vmcnt(14)), not for these.
+                st1_loads(std::integral_constant<int, 2 * R>{}, tid, y0 + k5TY, pre_p, pre_f);
+            }
             const float *bc = &s_pc[(NY * ty) * PW + 2 * tx];
             patch5_sums<float, NY>([&](int i, float (&row)[6]) { load_f1(bc + i * PW, row); }, sC);
         } else {
@@ -1223,6 +1378,7 @@ __global__ __launch_bounds__(256) OFLK_STAMP_OCC void k_lkw(LkArgs a)
             }
         }
 
+        probe<3>(s_mem);
         OFLK_STAMP(12);   // [12] stage 3: window sums
         const int gxb = x0 + 2 * tx;
         float su = 0.0f, sv = 0.0f;

@@ -66,7 +66,7 @@ def main():
     nblk = L.oflk_debug_stamps(plan._h, None, 0)
     raw = np.zeros((nblk, 4, 8, 16), np.uint32)
     L.oflk_debug_stamps(plan._h, raw.ctypes.data_as(ctypes.c_void_p), nblk)
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 2:   # the raw stamps (17 MB) only on request
         np.save(Path(sys.argv[1]).with_suffix(".raw.npy"), raw)
     ntile = raw[:, :, 0, 15].astype(int)              # tiles the block walked (0 = block exited at once)
     sums = {i: 0.0 for i in ORDER}
