@@ -3,7 +3,12 @@
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1
 the driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints
-ONE JSON line.
+ONE JSON line.  Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment),
+bench.py launches those N ranks itself: the parent starts ``python -m torch.distributed.run
+--nproc-per-node N bench.py ...`` as a CHILD process before anything touches the GPU, relays
+rank 0's JSON line and the child's exit code.  ``--multi inproc`` is the other multi-GPU
+form of the same job: ONE process, one plan per GPU on its shard of the pairs (what
+oflk_pyramidal_batch_multi does inside the library, here with device-resident shards).
 
 Workloads (``--config``):
   1080p (default)  BASELINE.json configs[2], the config the metric is quoted on: batches of
@@ -24,6 +29,9 @@ Extra objects in the JSON line:
   roofline_pyr  the same for the fused pyramid kernel (fp64-bound by SciPy's arithmetic)
   cpu_baseline  the CPU oracle (a bit-exact port of the reference's NumPy/SciPy arithmetic) timed on
                 this host on a bounded sample (N = 1 only)
+  epe_vs_reference  the parity half of the metric: the 13 committed verification patterns through the HIP
+                path (outside the timed region), compared with the digests / dense flows the reference produced
+                (tests/golden/: fixtures are data; no oracle involved)
 """
 from __future__ import annotations
 
@@ -112,6 +120,152 @@ def live_traffic(pairs: int, shape, timeout_s: int = 240) -> dict | None:
             "launches_averaged": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
 
 
+def self_launch(argv) -> int:
+    """`python bench.py --gpus N` (N > 1) started without a launcher: run the N ranks as a child
+    `python -m torch.distributed.run` job, relay its output.  The parent never touches the GPU."""
+    import socket
+    import subprocess
+
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    with socket.socket() as sk:   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    json_lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1])
+    return r.returncode
+
+
+def epe_vs_reference() -> dict | None:
+    """BASELINE metric, second half ("+ EPE vs Python ref"): the 13 verification patterns (tests/golden/
+    patterns_320x240.npz) through the HIP path, single-scale and pyramidal, against what the reference produced on
+    them: sha256 digests of its 26 flow fields (reference_13patterns.json) and its dense translate_medium flows."""
+    import hashlib
+
+    import numpy as np
+
+    gold = ROOT / "tests" / "golden"
+    try:
+        z = np.load(gold / "patterns_320x240.npz")
+        ref = json.loads((gold / "reference_13patterns.json").read_text())["patterns"]
+        dense = np.load(gold / "dense_translate_medium.npz")
+    except Exception:
+        return None
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+
+    def digest(a):
+        return hashlib.sha256((np.ascontiguousarray(a, np.float32) + np.float32(0.0)).tobytes()).hexdigest()
+
+    equal, total, iters_equal, worst = 0, 0, 0, 0.0
+    p = z["frame_0"].astype(np.float32)
+    for name, r in ref.items():
+        c = z[f"frame_1__{name}"].astype(np.float32)
+        u, v = K.lucas_kanade_single_scale(p, c, 5)
+        ok_s = digest(u) == r["single_scale"]["u_sha256"] and digest(v) == r["single_scale"]["v_sha256"]
+        pu, pv, _, runs = P.lucas_kanade_pyramidal_with_log(p, c, 3, 5, 3)
+        ok_p = digest(pu) == r["pyramidal"]["u_sha256"] and digest(pv) == r["pyramidal"]["v_sha256"]
+        equal += int(ok_s) + int(ok_p)
+        total += 2
+        iters_equal += int(list(runs) == r["pyramidal"]["iters_run"])
+        if name == "translate_medium":
+            for (a, b2, ku, kv) in ((u, v, "single_u", "single_v"), (pu, pv, "pyr_u", "pyr_v")):
+                worst = max(worst, float(np.mean(np.sqrt((a.astype(np.float64) - dense[ku]) ** 2 + (b2.astype(np.float64) - dense[kv]) ** 2))))
+    # equal digests = the reference's flow value for value: EPE exactly 0 on that field
+    return {"patterns": len(ref), "flow_fields": total, "digests_equal": equal, "iteration_counts_equal": iters_equal,
+            "max_mean_epe": worst if equal == total else None, "mean_epe_dense_translate_medium": worst, "tolerance": 1e-4,
+            "source": "tests/golden/reference_13patterns.json, dense_translate_medium.npz (made by importing the reference)"}
+
+
+def run_inproc(args) -> None:
+    """--multi inproc: the same job in ONE process, a plan per GPU on its shard of the pairs (device-resident), every
+    step enqueued on all GPUs before any is waited for.  value = job pixels / wall time over all GPUs."""
+    import numpy as np
+    import torch
+
+    import _oflk
+    from oflk_dist import job_layout
+    from oflk_synth import synth_pair
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU path exists)")
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if args.force_device is None and n > have:
+        raise SystemExit(f"--gpus {n} but {have} GPU(s) visible")
+    L, K = args.levels, args.iters
+    shards = []
+    host = None
+    for r in range(n):
+        lay = job_layout(args.config, r, n, args.pairs, args.height, args.width)
+        d = args.force_device if args.force_device is not None else r
+        dev = torch.device("cuda", d)
+        if host is None:
+            host = [synth_pair(lay.height, lay.width, pair_index=i) for i in range(2)]
+        with torch.cuda.device(dev):
+            prev = torch.empty((lay.pairs_local, lay.height, lay.width), dtype=torch.float32, device=dev)
+            curr = torch.empty_like(prev)
+            hp = [(torch.from_numpy(p).to(dev), torch.from_numpy(c).to(dev)) for p, c in host]
+            for b in range(lay.pairs_local):
+                p, c = hp[(lay.pair_begin + b) % len(hp)]
+                prev[b].copy_(p)
+                curr[b].copy_(c)
+            del hp
+            u, v = torch.empty_like(prev), torch.empty_like(prev)
+            stream = torch.cuda.Stream(device=dev)
+            plan = _oflk.Plan(d, lay.pairs_local, lay.height, lay.width, L, args.window, K)
+        shards.append((lay, dev, prev, curr, u, v, stream, plan))
+
+    def step():
+        for lay, dev, prev, curr, u, v, stream, plan in shards:
+            plan.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream.cuda_stream)
+
+    def sync():
+        for sh in shards:
+            sh[6].synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    lay0 = shards[0][0]
+    H, W = lay0.height, lay0.width
+    pairs = sum(sh[0].pairs_local for sh in shards)
+    abs_u = sum(float(sh[4].abs().sum(dtype=torch.float64).item()) for sh in shards)
+    out = {"metric": "Mpix/s dense flow (1080p pyramidal)" if (H, W) == (1080, 1920) else "Mpix/s dense flow",
+           "value": round(pairs * H * W * args.steps / elapsed / 1e6, 1), "unit": "Mpix/s", "n_gpus": n, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+           "scaling": lay0.scaling, "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic" if args.force_device is None else "synthetic (REHEARSAL: not a measurement)",
+           "config": {"workload": f"{W}x{H} frame pairs, {L}-level pyramidal LK, {args.window}x{args.window} window, {K} iterations/level",
+                      "name": lay0.config, "what": lay0.label, "pairs_per_step_job": pairs,
+                      "pairs_per_gpu_per_step": [sh[0].pairs_local for sh in shards],
+                      "parallelism": f"frame-pair sharding x{n}, one process, a plan and a stream per GPU (--multi inproc)"},
+           "job_stats": {"pairs_per_step": pairs, "mean_abs_u": round(abs_u / (pairs * H * W), 6)},
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out))
+    for sh in shards:
+        sh[7].close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,7 +287,15 @@ def main() -> None:
     # every rank on one device -- exercises the N > 1 code path end to end; the numbers of such a run mean nothing
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--force-device", type=int, default=None, help="use this GPU on every rank (rehearsal only)")
+    ap.add_argument("--multi", default="ranks", choices=["ranks", "inproc"],
+                    help="N > 1: one process per GPU (default) or ONE process with a plan per GPU")
+    ap.add_argument("--no-parity", action="store_true", help="skip the 13-pattern EPE check after the timed region")
     args = ap.parse_args()
+    if args.gpus > 1 and args.multi == "ranks" and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:]))   # before torch / the GPU are touched
+    if args.gpus > 1 and args.multi == "inproc":
+        run_inproc(args)
+        return
 
     import numpy as np
     import torch  # first: liboflk then binds to the HIP runtime torch already loaded
@@ -307,6 +469,11 @@ def main() -> None:
             cpu["all_cores"] = {"value": round(n * H * W / (c1 - c0) / 1e6, 4), "cores": nt}
             O.set_threads(1)
 
+    parity = None
+    if rank == 0 and not args.no_parity:
+        if local_rank != 0:
+            _oflk.check(_oflk.lib().oflk_set_device(local_rank))
+        parity = epe_vs_reference()
     if rank == 0:
         out = {
             "metric": "Mpix/s dense flow (1080p pyramidal)" if (H, W) == (1080, 1920) else "Mpix/s dense flow",
@@ -333,6 +500,7 @@ def main() -> None:
             "job_stats": job_stats,
             "one_pair_per_call": one_pair,
             "cpu_baseline": cpu,
+            "epe_vs_reference": parity,
         }
         print(json.dumps(out))
     plan.close()

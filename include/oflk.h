@@ -198,7 +198,8 @@ int oflk_plan_read_log(oflk_plan *plan, float *residual_log, int *iters_run, voi
 
 /* After oflk_plan_pyramidal + read_log: uncertain[b*levels + l] has bit k set when the early-exit test
  * after iteration k of level l (python/lucas_kanade_pyramidal.py:221-223) was decided with a mean
- * within 5e-5 (relative) of the 0.01 threshold.  The reference sums np.mean in fp32 (pairwise, in
+ * within the level's band around the 0.01 threshold: max(5e-5, (ceil(npix / 8192) + 32) * 2^-24) relative, i.e.
+ * 5e-5 up to 6.9 Mpx levels, 6.2e-5 at 4K, 2.4e-4 at 8K.  The reference sums np.mean in fp32 (pairwise, in
  * 8192-element pieces), the device in exact fixed point; the two can only decide differently inside
  * that band, so 0 everywhere means "provably the reference's iteration counts".  Synchronises. */
 int oflk_plan_read_uncertain(oflk_plan *plan, int *uncertain, void *stream);

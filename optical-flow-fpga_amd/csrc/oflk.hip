@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -288,7 +289,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         HIP_TRY(hipGetLastError());
         return OFLK_OK;
     }
-    static const int cap_env = getenv("OFLK_TPB") ? atoi(getenv("OFLK_TPB")) : 8;
+    constexpr int cap_env = 8;   // tiles per chained block at most (12 / 16 were measured: no change)
     const long resident = 1024;  // 256 CUs x 4 blocks
     const long per_slot = (long)B * tiles_x * tiles_y / resident;
     int cap = MODE == MODE_GRADS ? 1 : (int)std::min<long>(std::max(1, cap_env), per_slot / 5);
@@ -666,7 +667,7 @@ OFLK_API int oflk_plan_single_scale(oflk_plan *p, const float *d_prev, const flo
     return plan_single_scale(p, d_prev, d_curr, false, d_u, d_v, (hipStream_t)stream);
 }
 
-// BASELINE config 5: fp16 gradients / accumulators (k_lk16).  pixel_max bounds the frame values.
+// BASELINE config 5: fp16 gradients / accumulators (k_lk16d).  pixel_max bounds the frame values.
 OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, const float *d_curr, float *d_u, float *d_v,
                                          float pixel_max, void *stream)
 {
@@ -677,91 +678,46 @@ OFLK_API int oflk_plan_single_scale_fp16(oflk_plan *p, const float *d_prev, cons
     // s_g = 2^-k, the largest power of two (<= 1) with taps * (pixel_max / 2 * s_g)^2 <= 60000
     int k = 0;
     while ((double)taps * std::pow(0.5 * (double)pixel_max * std::ldexp(1.0, -k), 2.0) > 60000.0) k++;
-    Lk16Args a{};
-    a.prev = d_prev; a.curr = d_curr;
-    a.u = d_u; a.v = d_v;
-    a.H = p->H; a.W = p->W; a.B = p->B;
-    a.s_g = (float)std::ldexp(1.0, -k);
-    a.s_t = 0.5f * a.s_g;
-    a.det_thr = (float)(1e-4 * std::ldexp(1.0, -4 * k));
+    // one wave per (strip of 128 - 4 ceil(R/2) output columns, segment of Hs rows): two columns per lane (k_lk16d;
+    // 7x7: 77 VGPRs = 6 waves per SIMD, halo 6 %).  Segments are sized so that the launch is a whole number of
+    // rounds of the chip's wave slots at the kernel's occupancy, with ~64 rows each (a segment pays 2R extra rows
+    // of loads).
+    Lk16sArgs g{};
+    g.prev = d_prev; g.curr = d_curr; g.u = d_u; g.v = d_v;
+    g.H = p->H; g.W = p->W; g.B = p->B;
+    g.s_g = (float)std::ldexp(1.0, -k);
+    g.s_t = 0.5f * g.s_g;
+    g.det_thr = (float)(1e-4 * std::ldexp(1.0, -4 * k));
     hipStream_t s = (hipStream_t)stream;
     Prof pr(p, s, KC_LK_SINGLE);
-    const bool tiled = getenv("OFLK_LK16_TILED") != nullptr;   // development switch: the LDS-tiled form (k_lk16)
-    if (!tiled) {
-        // streaming form: one wave per (strip of 64 - 2R output columns, segment of Hs rows).  Segments are sized
-        // so that the launch is a whole number of rounds of the chip's 8192 wave slots (256 CUs x 4 SIMDs x 8),
-        // with ~64 rows each (a segment pays 2R extra rows of loads).
-        Lk16sArgs g{};
-        g.prev = d_prev; g.curr = d_curr; g.u = d_u; g.v = d_v;
-        g.H = a.H; g.W = a.W; g.B = a.B;
-        g.s_g = a.s_g; g.s_t = a.s_t; g.det_thr = a.det_thr;
-        // two columns per lane (k_lk16d; 7x7: 77 VGPRs = 6 waves per SIMD, halo 6 %, 116-128 against 124-144 us at 8K;
-        // 11x11: 138 against 182); OFLK_LK16_COLS=1 runs the one-column form instead (k_lk16s: 8 waves, halo 9-12.5 %;
-        // development switch)
-        static const int force_cols = getenv("OFLK_LK16_COLS") ? atoi(getenv("OFLK_LK16_COLS")) : 0;
-        const bool dbl = force_cols != 1;
-        const int outw = dbl ? 2 * (64 - 2 * ((hw + 2) / 2)) : 64 - 2 * (hw + 1);
-        const long strips = ((long)a.W + outw - 1) / outw * a.B;
-        const long slots = dbl ? (hw <= 2 ? 8192 : hw == 3 ? 6144 : hw == 4 ? 5120 : 4096) : 8192;   // wave slots of the chip at the kernel's occupancy (8 / 8 / 6 / 5 / 4 waves per SIMD)
-        long segs = ((long)a.H + 63) / 64;
-        const double rounds = (double)(strips * segs) / (double)slots;
-        if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
-        else segs = std::max(segs, std::min(slots / std::max<long>(strips, 1), std::max<long>(1, a.H / 40)));   // fill the one round, >= 40 rows each
-        segs = std::min<long>(segs, std::max<long>(1, a.H / 8));
-        if (const char *e = getenv("OFLK_LK16_HS")) segs = std::max<long>(1, ((long)a.H + atol(e) - 1) / std::max<long>(1, atol(e)));
-        g.Hs = (int)(((long)a.H + segs - 1) / segs);
-        g.segs = (a.H + g.Hs - 1) / g.Hs;
-        const long nwave = strips * g.segs;
-        dim3 sgrid((unsigned)((nwave + 3) / 4)), sblock(256);
-        if (dbl) {
-            auto al8 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
-            const bool vec8 = (a.W & 1) == 0 && a.W >= 2 && al8(d_prev) && al8(d_curr) && al8(d_u) && al8(d_v);   // 8-byte column pairs
+    const int outw = 2 * (64 - 2 * ((hw + 2) / 2));
+    const long strips = ((long)g.W + outw - 1) / outw * g.B;
+    const long slots = hw <= 2 ? 8192 : hw == 3 ? 6144 : hw == 4 ? 5120 : 4096;   // wave slots of the chip at 8 / 8 / 6 / 5 / 4 waves per SIMD
+    long segs = ((long)g.H + 63) / 64;
+    const double rounds = (double)(strips * segs) / (double)slots;
+    if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
+    else segs = std::max(segs, std::min(slots / std::max<long>(strips, 1), std::max<long>(1, g.H / 40)));   // fill the one round, >= 40 rows each
+    segs = std::min<long>(segs, std::max<long>(1, g.H / 8));
+    g.Hs = (int)(((long)g.H + segs - 1) / segs);
+    g.segs = (g.H + g.Hs - 1) / g.Hs;
+    const long nwave = strips * g.segs;
+    dim3 sgrid((unsigned)((nwave + 3) / 4)), sblock(256);
+    auto al8 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
+    const bool vec8 = (g.W & 1) == 0 && g.W >= 2 && al8(d_prev) && al8(d_curr) && al8(d_u) && al8(d_v);   // 8-byte column pairs
 #define OFLK_LAUNCH_LK16D(HWV)                                                                 \
     do {                                                                                       \
         if (vec8) hipLaunchKernelGGL((k_lk16d<HWV, true>), sgrid, sblock, 0, s, g);            \
         else hipLaunchKernelGGL((k_lk16d<HWV, false>), sgrid, sblock, 0, s, g);                \
     } while (0)
-            switch (hw) {
-                case 1: OFLK_LAUNCH_LK16D(1); break;
-                case 2: OFLK_LAUNCH_LK16D(2); break;
-                case 3: OFLK_LAUNCH_LK16D(3); break;
-                case 4: OFLK_LAUNCH_LK16D(4); break;
-                case 5: OFLK_LAUNCH_LK16D(5); break;
-                default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
-            }
-#undef OFLK_LAUNCH_LK16D
-            HIP_TRY(hipGetLastError());
-            return OFLK_OK;
-        }
-        switch (hw) {
-            case 1: hipLaunchKernelGGL((k_lk16s<1>), sgrid, sblock, 0, s, g); break;
-            case 2: hipLaunchKernelGGL((k_lk16s<2>), sgrid, sblock, 0, s, g); break;
-            case 3: hipLaunchKernelGGL((k_lk16s<3>), sgrid, sblock, 0, s, g); break;
-            case 4: hipLaunchKernelGGL((k_lk16s<4>), sgrid, sblock, 0, s, g); break;
-            case 5: hipLaunchKernelGGL((k_lk16s<5>), sgrid, sblock, 0, s, g); break;
-            default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
-        }
-        HIP_TRY(hipGetLastError());
-        return OFLK_OK;
-    }
-    const int tiles_x = (a.W + k16TX - 1) / k16TX, tiles_y = (a.H + k16TY - 1) / k16TY;
-    dim3 grid((unsigned)(tiles_x * tiles_y * a.B));
-    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool vec = (a.W & 3) == 0 && al16(d_prev) && al16(d_curr) && al16(d_u) && al16(d_v);
-#define OFLK_LAUNCH_LK16(HWV)                                                       \
-    do {                                                                            \
-        if (vec) hipLaunchKernelGGL((k_lk16<HWV, true>), grid, dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL((k_lk16<HWV, false>), grid, dim3(256), 0, s, a);     \
-    } while (0)
     switch (hw) {
-        case 1: OFLK_LAUNCH_LK16(1); break;
-        case 2: OFLK_LAUNCH_LK16(2); break;
-        case 3: OFLK_LAUNCH_LK16(3); break;
-        case 4: OFLK_LAUNCH_LK16(4); break;
-        case 5: OFLK_LAUNCH_LK16(5); break;
+        case 1: OFLK_LAUNCH_LK16D(1); break;
+        case 2: OFLK_LAUNCH_LK16D(2); break;
+        case 3: OFLK_LAUNCH_LK16D(3); break;
+        case 4: OFLK_LAUNCH_LK16D(4); break;
+        case 5: OFLK_LAUNCH_LK16D(5); break;
         default: return fail(OFLK_ERR_UNSUPPORTED, "half window %d not built", hw);
     }
-#undef OFLK_LAUNCH_LK16
+#undef OFLK_LAUNCH_LK16D
     HIP_TRY(hipGetLastError());
     return OFLK_OK;
 }
@@ -910,8 +866,9 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
         e.uncertain = p->uncertain();
         for (int l = 0; l < L; l++) {
             const double t = (double)e.thr[l];
-            e.guard_lo[l] = (unsigned long long)std::floor(t * (1.0 - kDecisionGuard));
-            e.guard_hi[l] = (unsigned long long)std::ceil(t * (1.0 + kDecisionGuard));
+            const double g = decision_guard(e.counts[l]);
+            e.guard_lo[l] = (unsigned long long)std::floor(t * (1.0 - g));
+            e.guard_hi[l] = (unsigned long long)std::ceil(t * (1.0 + g));
         }
         e.plane = (size_t)p->H * p->W;
         // few blocks per pair: the copy is the rare case, the common one is "nothing to do"
@@ -1228,6 +1185,11 @@ struct HostCtx {
     size_t io_elems = 0;
     unsigned char *u8[2] = {nullptr, nullptr};              // device uint8 frames
     size_t u8_elems = 0;
+    // chunked host calls (run_batch_chunked): two slots of chunk-sized frames in / flow out, three streams
+    void *ring_in[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [slot][prev, curr], PIXELS
+    float *ring_out[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [slot][u, v]
+    size_t ring_in_bytes = 0, ring_out_elems = 0;
+    hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
 };
 HostCtx g_ctx[kMaxDevices];
 
@@ -1305,6 +1267,47 @@ int host_u8(HostCtx &c, size_t need)
     return OFLK_OK;
 }
 
+int host_ring(HostCtx &c, size_t in_bytes, size_t out_elems)
+{
+    if (!c.s_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&c.s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c.s_comp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c.s_out, hipStreamNonBlocking));
+    }
+    size_t tot = 0;
+    if (in_bytes > c.ring_in_bytes) {
+        for (auto &slot : c.ring_in)
+            for (auto &q : slot) {
+                if (q) (void)hipFree(q);
+                q = nullptr;
+            }
+        c.ring_in_bytes = 0;
+        for (auto &slot : c.ring_in)
+            for (auto &q : slot) {
+                unsigned char *b = nullptr;
+                int rc = dmalloc(&b, in_bytes, &tot);
+                if (rc) return rc;
+                q = b;
+            }
+        c.ring_in_bytes = in_bytes;
+    }
+    if (out_elems > c.ring_out_elems) {
+        for (auto &slot : c.ring_out)
+            for (auto &q : slot) {
+                if (q) (void)hipFree(q);
+                q = nullptr;
+            }
+        c.ring_out_elems = 0;
+        for (auto &slot : c.ring_out)
+            for (auto &q : slot) {
+                int rc = dmalloc(&q, out_elems, &tot);
+                if (rc) return rc;
+            }
+        c.ring_out_elems = out_elems;
+    }
+    return OFLK_OK;
+}
+
 int check_hw(const void *a, const void *b, int H, int W)
 {
     if (!a || !b) return fail(OFLK_ERR_INVALID, "NULL array argument");
@@ -1312,6 +1315,132 @@ int check_hw(const void *a, const void *b, int H, int W)
     if ((size_t)H * (size_t)W >= ((size_t)1 << 30) || H >= (1 << 24) || W >= (1 << 24))
         return fail(OFLK_ERR_UNSUPPORTED, "frames of 2^30 pixels or more are not supported");  // 32-bit byte offsets
     return OFLK_OK;
+}
+
+// A large host batch in chunks, so that the PCIe link works in both directions while the GPU computes:
+//   main thread    H2D(k+1) on s_in   |  kernels(k) on s_comp  |  (exit decisions, log of chunk k)
+//   second thread                         D2H(k-1) on s_out
+// Two slots of chunk-sized device buffers; a chunk's inputs wait for the kernels two chunks back, its kernels for
+// the D2H two chunks back.  The callers' arrays are ordinary pageable memory: a copy from / to them holds its host
+// thread until it is done, which is why the two directions have a thread each.  Frame pairs are independent, so
+// the results do not depend on the cut (tests/test_gpu_round3.py).  A synchronous float32 call moves 33 MB per
+// 1080p pair over the link, half of it each way: overlapped, the floor is one direction's time.
+template <class PIXELS>
+int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *curr, int B, int C, int H, int W, int levels,
+                      int window_size, int iters, float *u, float *v, float *residual_log, int *iters_run)
+{
+    constexpr bool U8 = sizeof(PIXELS) == 1;
+    const bool single = levels == 0;
+    const int Lp = single ? 1 : levels, Kp = single ? 0 : iters;
+    const int Lc = std::max(levels, 1), Kc = std::max(iters, 1);
+    const size_t plane = (size_t)H * W;
+    const int nchunk = (B + C - 1) / C;
+    int rc;
+    if ((rc = host_ring(*c, (size_t)C * plane * sizeof(PIXELS), (size_t)C * plane))) return rc;
+    oflk_plan *pc = nullptr, *pt = nullptr;
+    if ((rc = host_plan(*c, dev, C, H, W, Lp, window_size, Kp, &pc))) return rc;
+    const int tail = B - (nchunk - 1) * C;
+    if (tail != C && (rc = host_plan(*c, dev, tail, H, W, Lp, window_size, Kp, &pt))) return rc;
+    if (tail != C && (rc = host_plan(*c, dev, C, H, W, Lp, window_size, Kp, &pc))) return rc;   // (the cache may have moved it)
+
+    hipEvent_t ev_in[2], ev_out[2];
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
+    }
+    // hand-over to the D2H thread: chunks [0, computed) are ready to leave, chunks [0, copied) have left
+    std::mutex mu;
+    std::condition_variable cv;
+    int computed = 0, copied = 0, out_rc = OFLK_OK;
+    bool stop = false;
+    std::string out_msg;
+    std::thread out_thread([&]() {
+        if (ensure_device(dev)) { std::lock_guard<std::mutex> g(mu); out_rc = OFLK_ERR_HIP; out_msg = t_err; cv.notify_all(); return; }
+        for (int k = 0; k < nchunk; k++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return computed > k || stop; });
+                if (computed <= k) return;
+            }
+            const int slot = k & 1, nb = k == nchunk - 1 ? tail : C;
+            const size_t off = (size_t)k * C * plane, bytes = (size_t)nb * plane * sizeof(float);
+            hipError_t e = hipMemcpyAsync(u + off, c->ring_out[slot][0], bytes, hipMemcpyDeviceToHost, c->s_out);
+            if (e == hipSuccess) e = hipMemcpyAsync(v + off, c->ring_out[slot][1], bytes, hipMemcpyDeviceToHost, c->s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->s_out);
+            std::lock_guard<std::mutex> g(mu);
+            if (e != hipSuccess) {
+                out_rc = OFLK_ERR_HIP;
+                out_msg = std::string("D2H of a chunk: ") + hipGetErrorString(e);
+                cv.notify_all();
+                return;
+            }
+            copied = k + 1;
+            cv.notify_all();
+        }
+    });
+    auto finish = [&](int code) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        out_thread.join();
+        for (int i = 0; i < 2; i++) {
+            (void)hipEventDestroy(ev_in[i]);
+            (void)hipEventDestroy(ev_out[i]);
+        }
+        if (code == OFLK_OK && out_rc != OFLK_OK) return fail(out_rc, "%s", out_msg.c_str());
+        return code;
+    };
+    auto h2d = [&](int k) -> int {
+        const int slot = k & 1, nb = k == nchunk - 1 ? tail : C;
+        const size_t off = (size_t)k * C * plane, bytes = (size_t)nb * plane * sizeof(PIXELS);
+        HIP_TRY(hipMemcpyAsync(c->ring_in[slot][0], prev + off, bytes, hipMemcpyHostToDevice, c->s_in));
+        HIP_TRY(hipMemcpyAsync(c->ring_in[slot][1], curr + off, bytes, hipMemcpyHostToDevice, c->s_in));
+        HIP_TRY(hipEventRecord(ev_in[slot], c->s_in));
+        return OFLK_OK;
+    };
+    int resolved_total = 0;
+    if ((rc = h2d(0))) return finish(rc);
+    for (int k = 0; k < nchunk; k++) {
+        const int slot = k & 1, nb = k == nchunk - 1 ? tail : C;
+        oflk_plan *p = nb == C ? pc : pt;
+        if (k >= 2) {   // the slot's flow buffers are free once chunk k-2 has left
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return copied >= k - 1 || out_rc != OFLK_OK; });
+            if (out_rc != OFLK_OK) { g.unlock(); return finish(OFLK_OK); }
+        }
+        if ((rc = hipStreamWaitEvent(c->s_comp, ev_in[slot], 0)) != hipSuccess) return finish(fail(OFLK_ERR_HIP, "hipStreamWaitEvent"));
+        const void *dp = c->ring_in[slot][0], *dc = c->ring_in[slot][1];
+        float *du = c->ring_out[slot][0], *dv = c->ring_out[slot][1];
+        rc = single ? plan_single_scale(p, dp, dc, U8, du, dv, c->s_comp) : plan_pyramidal(p, dp, dc, U8, du, dv, c->s_comp);
+        if (rc) return finish(rc);
+        // the next chunk's frames travel while this one is computed (its slot's kernels, chunk k-1, were waited for below)
+        if (k + 1 < nchunk && (rc = h2d(k + 1))) return finish(rc);
+        if (!single && iters > 0) {
+            int n = 0;
+            if ((rc = resolve_uncertain(p, dp, dc, U8, du, dv, c->s_comp, &n))) return finish(rc);
+            resolved_total += n;
+        }
+        if (single) {
+            if (hipStreamSynchronize(c->s_comp) != hipSuccess) return finish(fail(OFLK_ERR_HIP, "hipStreamSynchronize"));
+        } else {
+            rc = oflk_plan_read_log(p, residual_log ? residual_log + (size_t)k * C * Lc * Kc * 2 : nullptr,
+                                    iters_run ? iters_run + (size_t)k * C * Lc : nullptr, c->s_comp);
+            if (rc) return finish(rc);
+        }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            computed = k + 1;
+        }
+        cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return copied >= nchunk || out_rc != OFLK_OK; });
+    }
+    t_resolved += resolved_total;
+    return finish(OFLK_OK);
 }
 
 // One batch on one device, host pointers in and out.  PIXELS: float or unsigned char frames (the
@@ -1322,6 +1451,7 @@ int run_batch_on(int dev, const PIXELS *prev, const PIXELS *curr, int B, int H, 
                  int iters, float *u, float *v, float *residual_log, int *iters_run)
 {
     constexpr bool U8 = sizeof(PIXELS) == 1;
+    t_resolved = 0;   // of THIS call (oflk_last_resolved)
     int rc = check_hw(prev, curr, H, W);
     if (rc) return rc;
     if (!u || !v) return fail(OFLK_ERR_INVALID, "NULL output");
@@ -1330,6 +1460,13 @@ int run_batch_on(int dev, const PIXELS *prev, const PIXELS *curr, int B, int H, 
     std::unique_lock<std::mutex> lk;
     if ((rc = acquire(dev, &c, lk))) return rc;
     const bool single = levels == 0;
+    {
+        // chunks of ~32 MB of flow per plane (two 1080p pairs); worth it from four chunks on
+        const size_t pair_out = (size_t)H * W * sizeof(float);
+        const int C = (int)std::max<size_t>(1, ((size_t)32 << 20) / std::max<size_t>(pair_out, 1));
+        if (B >= 4 * C && (size_t)B * pair_out >= ((size_t)64 << 20))
+            return run_batch_chunked<PIXELS>(c, dev, prev, curr, B, C, H, W, levels, window_size, iters, u, v, residual_log, iters_run);
+    }
     oflk_plan *p = nullptr;
     if ((rc = host_plan(*c, dev, B, H, W, single ? 1 : levels, window_size, single ? 0 : iters, &p))) return rc;
     const size_t n = (size_t)B * H * W, obytes = n * sizeof(float);
@@ -1351,7 +1488,11 @@ int run_batch_on(int dev, const PIXELS *prev, const PIXELS *curr, int B, int H, 
                 : plan_pyramidal(p, dp, dc, U8, c->io[2], c->io[3], nullptr);
     if (rc) return rc;
     // exit decisions the device could not take with certainty are redone in NumPy's own summation order
-    if (!single && iters > 0 && (rc = resolve_uncertain(p, dp, dc, U8, c->io[2], c->io[3], nullptr, &t_resolved))) return rc;
+    if (!single && iters > 0) {
+        int n_res = 0;
+        if ((rc = resolve_uncertain(p, dp, dc, U8, c->io[2], c->io[3], nullptr, &n_res))) return rc;
+        t_resolved += n_res;
+    }
     HIP_TRY(hipMemcpyAsync(u, c->io[2], obytes, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipMemcpyAsync(v, c->io[3], obytes, hipMemcpyDeviceToHost, nullptr));
     if (single) {
@@ -1391,7 +1532,7 @@ int run_batch_multi(const PIXELS *prev, const PIXELS *curr, int B, int H, int W,
                                     iters_run);
     const size_t plane = (size_t)H * W;
     const int Lc = std::max(levels, 1), Kc = std::max(iters, 1);
-    std::vector<int> codes((size_t)n_gpus, OFLK_OK);
+    std::vector<int> codes((size_t)n_gpus, OFLK_OK), redone((size_t)n_gpus, 0);
     std::vector<std::string> msgs((size_t)n_gpus);
     std::vector<std::thread> workers;
     for (int g = 0; g < n_gpus; g++) {
@@ -1405,9 +1546,12 @@ int run_batch_multi(const PIXELS *prev, const PIXELS *curr, int B, int H, int W,
                                                     residual_log ? residual_log + (size_t)b0 * Lc * Kc * 2 : nullptr,
                                                     iters_run ? iters_run + (size_t)b0 * Lc : nullptr);
             if (codes[(size_t)g]) msgs[(size_t)g] = t_err;   // the worker's thread-local message
+            redone[(size_t)g] = t_resolved;                    // ... and its count of pairs redone
         });
     }
     for (auto &w : workers) w.join();
+    t_resolved = 0;
+    for (int g = 0; g < n_gpus; g++) t_resolved += redone[(size_t)g];
     for (int g = 0; g < n_gpus; g++)
         if (codes[(size_t)g]) return fail(codes[(size_t)g], "device %d: %s", g, msgs[(size_t)g].c_str());
     return OFLK_OK;

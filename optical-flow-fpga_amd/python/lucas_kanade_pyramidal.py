@@ -154,9 +154,9 @@ def lucas_kanade_pyramidal(
     shapes = pyramid_level_shapes(np.shape(frame_prev), num_levels)
     H, W = int(np.shape(frame_prev)[0]), int(np.shape(frame_prev)[1])
     key = (1, H, W, int(num_levels), int(window_size), int(num_iterations))
-    # exit decisions taken too close to the 0.01 threshold to be provably the reference's (see oflk.h)
-    flags = np.zeros(max(num_levels, 1), np.int32)
-    _oflk.check(_oflk.lib().oflk_pyramidal_last_uncertain(*key, flags.ctypes.data_as(_i32p)))
+    # exit decisions taken too close to the 0.01 threshold were redone by the library in NumPy's own summation order
+    # (oflk_plan_resolve_uncertain, see oflk.h): the result is the reference's either way; say so when it happened
+    resolved = int(_oflk.lib().oflk_last_resolved())
     _say(f"Building {num_levels}-level Gaussian pyramids...")
     _say("Pyramid levels:")
     for i, (h, w) in enumerate(shapes):
@@ -170,9 +170,9 @@ def lucas_kanade_pyramidal(
             _say(f"  Iteration {it+1}/{num_iterations}: mean residual = ({mu:.4f}, {mv:.4f})")
             if mu < 0.01 and mv < 0.01:
                 _say(f"  Converged after {it+1} iterations")
-            if int(flags[level]) >> it & 1:
-                _say(f"  note: this residual is within 5e-5 of the 0.01 exit threshold; the reference's fp32 "
-                     f"summation order could decide the other way")
+    if resolved:
+        _say("  note: an exit decision of this pair lay within the summation error of the 0.01 threshold and was "
+             "re-evaluated in NumPy's summation order")
     if os.environ.get("OFLK_DUMP_LEVELS", "0") == "1":
         _dump_levels(key, shapes, u, v)
     return u, v

@@ -517,3 +517,63 @@ def test_bench_multi_rank_rehearsal(config, ranks, expect_pairs):
     # whole-job value: pixels of ALL ranks over the MAX-rank time
     assert abs(j["value"] - expect_pairs * 120 * 160 * 2 / (j["ms_per_step"] * 2e-3) / 1e6) <= 1e-3 * j["value"]
     assert "REHEARSAL" in j["data"] and j["cpu_baseline"] is None
+
+
+def test_bench_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no launcher on the command line: the parent starts the two ranks as a child
+    torch.distributed.run job before touching the GPU and relays rank 0's ONE JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                          "--force-device", "0", "--height", "120", "--width", "160", "--pairs", "3", "--no-cpu-baseline",
+                          "--no-one-pair"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["pairs_per_step_job"] == 6 and "REHEARSAL" in j["data"]
+    # the parity half of the metric rides in the same line: the reference's 26 flow fields, value for value
+    e = j["epe_vs_reference"]
+    assert e["patterns"] == 13 and e["digests_equal"] == 26 and e["max_mean_epe"] == 0.0 and e["iteration_counts_equal"] == 13
+
+
+def test_bench_multi_inproc_rehearsal():
+    """--multi inproc: one process, a plan and a stream per GPU (here: twice GPU 0) on the shards of the 4k64 job"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--multi", "inproc", "--steps", "2", "--warmup", "1",
+                          "--force-device", "0", "--config", "4k64", "--height", "120", "--width", "160"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["pairs_per_step_job"] == 64
+    assert j["config"]["pairs_per_gpu_per_step"] == [32, 32] and j["job_stats"]["mean_abs_u"] > 0
+
+
+@pytest.mark.parametrize("win", [1, 12, 13, 25])
+def test_windows_without_a_kernel_are_refused_loudly(win):
+    """the reference takes any window_size (lucas_kanade_core.py:104-119); kernels exist for 3x3 ... 11x11 (sizes 2 ... 11),
+    every other size returns OFLK_ERR_UNSUPPORTED with the documented message (include/oflk.h), never a wrong flow"""
+    import _oflk
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+
+    a = np.zeros((32, 48), np.float32)
+    for call in (lambda: K.lucas_kanade_single_scale(a, a, win), lambda: P.lucas_kanade_pyramidal(a, a, 2, win, 1),
+                 lambda: _oflk.Plan(0, 1, 32, 48, 1, win, 0)):
+        with pytest.raises(_oflk.OflkError) as e:
+            call()
+        assert e.value.code == _oflk.OFLK_ERR_UNSUPPORTED
+        assert f"window_size {win} not built (kernels exist for 3x3 ... 11x11 windows)" in str(e.value)

@@ -187,3 +187,19 @@ def test_visualize_flow_parses_dumps_and_plots(tmp_path):
     out = tmp_path / "results" / "viz.png"
     VF.create_diagnostic_plot(str(frame), str(dump), str(out), 2.0, 0.0, stride=7)
     assert out.exists() and out.stat().st_size > 10_000
+
+
+def test_markdown_report_equals_the_reference_held_report(golden_dir):
+    """generate_markdown_table on the metrics the reference published (verification_baseline.json) reproduces the report
+    the reference holds next to them (python/verification_results.md, copied to tests/golden/ as data): same rows,
+    same number formats, same status words, same legend"""
+    import json
+
+    import optical_flow_verifier as V
+
+    base = json.loads((golden_dir / "verification_baseline.json").read_text())
+    results = list(base["patterns"].values())
+    ours = V.generate_markdown_table(results).strip().splitlines()
+    theirs = (golden_dir / "verification_results.md").read_text().strip().splitlines()
+    rows = lambda ls: [l.rstrip() for l in ls if l.strip()]
+    assert rows(ours) == rows(theirs)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the fp16 single-scale mode (BASELINE config 5 geometry by default), development tool.
 Usage (GPU box): python3 tools/fp16_bench.py [--height 4320 --width 7680 --window 7 --pairs 1 --reps 20]
-Environment switches of the library apply (OFLK_LK16_TILED=1: the LDS-tiled form; OFLK_LK16_HS=n: rows per segment)."""
+"""
 import argparse
 import sys
 import time
