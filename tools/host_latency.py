@@ -27,7 +27,34 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
+def batch_main(B=32, h=1080, w=1920):
+    """a batch of B pairs through the C ABI, host arrays in and out: large batches are cut into chunks whose H2D, kernels
+    and D2H overlap (csrc/oflk.hip run_batch_chunked)"""
+    import ctypes
+
+    import _oflk
+
+    L = _oflk.lib()
+    f32p, i32p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    pairs = [synth_pair(h, w, pair_index=i) for i in range(4)]
+    a = np.ascontiguousarray(np.stack([pairs[i % 4][0] for i in range(B)]))
+    b = np.ascontiguousarray(np.stack([pairs[i % 4][1] for i in range(B)]))
+    u, v = np.empty_like(a), np.empty_like(a)
+    log, runs = np.zeros((B, 3, 3, 2), np.float32), np.zeros((B, 3), np.int32)
+    tf = timed(lambda: _oflk.check(L.oflk_pyramidal_batch(a.ctypes.data_as(f32p), b.ctypes.data_as(f32p), B, h, w, 3, 5, 3,
+                                                          u.ctypes.data_as(f32p), v.ctypes.data_as(f32p), log.ctypes.data_as(f32p),
+                                                          runs.ctypes.data_as(i32p))), 5)
+    a8, b8 = a.astype(np.uint8), b.astype(np.uint8)
+    t8 = timed(lambda: _oflk.check(L.oflk_pyramidal_u8(a8.ctypes.data, b8.ctypes.data, B, h, w, 3, 5, 3, u.ctypes.data_as(f32p),
+                                                       v.ctypes.data_as(f32p), log.ctypes.data_as(f32p), runs.ctypes.data_as(i32p))), 5)
+    print(f"{B} x {w}x{h} pyramidal, one call, host to host: float32 frames {tf / B * 1e3:.3f} ms/pair ({B * h * w / tf / 1e6:.0f} Mpix/s, "
+          f"{a.nbytes * 4 / tf / 1e9:.1f} GB/s over PCIe), uint8 frames {t8 / B * 1e3:.3f} ms/pair ({B * h * w / t8 / 1e6:.0f} Mpix/s)")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "batch":
+        batch_main(*[int(x) for x in sys.argv[2:]])
+        return
     for (h, w) in ((480, 640), (1080, 1920), (2160, 3840)):
         a, b = synth_pair(h, w, pair_index=1)
         ts = timed(lambda: K.lucas_kanade_single_scale(a, b, 5), 20)
