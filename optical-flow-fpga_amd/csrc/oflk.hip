@@ -1033,6 +1033,14 @@ int resolve_pair(oflk_plan *p, int b, const void *d_prev_in, const void *d_curr_
     }
     HIP_TRY(hipMemcpyAsync(d_u + (size_t)b * N, x.u[L - 1], N * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_v + (size_t)b * N, x.v[L - 1], N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // the coarser levels' final flows where oflk_plan_read_level_flow looks for them: the interleaved slot the
+    // (new) iteration count of the level selects (strided copies: u into the .x, v into the .y of every float2)
+    for (int l = 0; l < L - 1; l++) {
+        const size_t n = p->npix(l);
+        float *dst = reinterpret_cast<float *>(p->fl(l, runs[(size_t)l] & 1) + (size_t)b * n);
+        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(float2), x.u[l], sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(dst + 1, sizeof(float2), x.v[l], sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, s));
+    }
     // the pair's log, iteration counts and (cleared) flags in the plan's state, where read_log looks
     HIP_TRY(hipMemcpyAsync(p->log() + (size_t)b * L * p->Kc() * 2, log.data(), log.size() * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(p->iters_run() + (size_t)b * L, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice, s));

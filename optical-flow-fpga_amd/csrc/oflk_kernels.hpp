@@ -1601,7 +1601,7 @@ struct PyrArgs {
 template <class PIX>
 __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
 {
-    __shared__ float s_in[kPIH * kPIW];   // stage A; reused for the blurred tile (stage C output)
+    __shared__ __attribute__((aligned(16))) float s_in[kPIH * kPIW];   // stage A (8-byte column-pair writes); reused for the blurred tile (stage C output)
     __shared__ float s_v[kPBH * kPVS];
     float *s_h = s_in;
     static_assert(kPBH * kPHS <= kPIH * kPIW, "blurred tile must fit the input tile's storage");

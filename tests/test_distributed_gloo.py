@@ -160,8 +160,10 @@ def test_bench_layout_timing_and_aggregation_two_ranks(tmp_path, oracle):
 
 
 def test_bench_refuses_a_world_size_mismatch():
-    """`--gpus N` with another WORLD_SIZE used to warn and report a different job."""
+    """`--gpus N` under a launcher that started another number of ranks used to warn and report a different
+    job.  (With NO launcher in the environment bench.py starts its own N ranks: tests/test_gpu_round2.py.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=300, env=env)
     assert out.returncode == 2 and "WORLD_SIZE=1" in out.stderr and not out.stdout.strip()

@@ -1,5 +1,6 @@
 """BASELINE.json config 5 (7680x4320 pair, 7x7 window, fp16 gradients / accumulators): the opt-in
-reduced-precision single-scale mode against the exact fp32 path.
+reduced-precision single-scale mode against the exact result -- on the 13 patterns the exact flow is the CPU ORACLE's
+(pinned to the reference by tests/test_oracle_golden.py), so a regression shared by both HIP paths cannot hide.
 
 The reference has no such mode (its arithmetic is fp32, lucas_kanade_core.py:110-133), so the bar is
 not equality: SURVEY.md section 7 -- "parity target there is EPE vs fp32 reference REPORTED, not 1e-4".
@@ -9,10 +10,9 @@ in 49-tap sums), not tuning knobs:
 
   * well-conditioned pixels (|det| of the exact normal matrix among the upper half of the frame's
     values): mean EPE <= 0.01 px   (measured: <= 0.0042 px over the 13 patterns, 5x5 and 7x7)
-  * all pixels: MEDIAN EPE <= 0.01 px (measured: <= 0.0023 px; the mean over all pixels -- measured
-    <= 0.0072 px -- is reported but not bounded: where
-    det ~ 0 the exact flow itself reaches thousands of pixels -- 7078 px on translate_extreme -- and any
-    rounding moves it by pixels)
+  * all pixels: MEDIAN EPE <= 0.01 px (measured: <= 0.0023 px) and MEAN EPE <= 0.02 px (measured: <= 0.0072 px; where
+    det ~ 0 the exact flow itself reaches thousands of pixels -- 7078 px on translate_extreme -- and any rounding moves
+    it by pixels, so the bound on the mean is a regression gate at ~3x the measured value, not a property of fp16)
   * the mode keeps the reference's border and det-threshold semantics: borders exactly 0.
 
 Numbers of one run are written to gpurun_out/fp16_epe.json (copied to profiles/ by the refresh script).
@@ -32,6 +32,7 @@ PATTERNS = ["translate_small", "translate_medium", "translate_large", "translate
             "translate_extreme"]
 TOL_WELL_CONDITIONED_MEAN = 0.01   # px
 TOL_MEDIAN = 0.01                  # px
+TOL_MEAN_ALL = 0.02                # px: regression gate, ~3x what is measured
 
 _report = {}
 
@@ -50,10 +51,10 @@ def _dets(p, c, win):
     return sxx * syy - sxy * sxy
 
 
-def _epe_stats(p, c, win):
+def _epe_stats(p, c, win, exact=None):
     import lucas_kanade_core as K
 
-    u, v = K.lucas_kanade_single_scale(p, c, win)
+    u, v = exact if exact is not None else K.lucas_kanade_single_scale(p, c, win)
     hu, hv = K.lucas_kanade_single_scale_fp16(p, c, win, 255.0)
     assert np.isfinite(hu).all() and np.isfinite(hv).all()
     hw = win // 2
@@ -76,12 +77,13 @@ def suite(golden_dir):
 
 @pytest.mark.parametrize("name", PATTERNS)
 @pytest.mark.parametrize("win", [7, 5])
-def test_fp16_epe_on_the_13_patterns(suite, name, win):
+def test_fp16_epe_on_the_13_patterns(suite, oracle, name, win):
     p, c = suite["frame_0"].astype(np.float32), suite[f"frame_1__{name}"].astype(np.float32)
-    st = _epe_stats(p, c, win)
+    st = _epe_stats(p, c, win, exact=oracle.lucas_kanade_single_scale(p, c, win))   # the oracle's exact flow
     _report[f"{name} {win}x{win}"] = st
     assert st["median_epe_all"] <= TOL_MEDIAN, st
     assert st["mean_epe_well_conditioned"] <= TOL_WELL_CONDITIONED_MEAN, st
+    assert st["mean_epe_all"] <= TOL_MEAN_ALL, st
 
 
 def test_fp16_at_8k_config5():
