@@ -225,6 +225,20 @@ int oflk_last_resolved(void);
  * visualize_pyramid_level at python/lucas_kanade_pyramidal.py:226.  Synchronises. */
 int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, float *v, void *stream);
 
+/* Arithmetic of the plan's fp64 stages.  OFLK_ARITH_EXACT (the default, and what every host entry point uses): SciPy's
+ * operation sequence, every operation rounded on its own -- results equal the reference's value for value.
+ * OFLK_ARITH_CONTRACTED (opt-in): the Gaussian pyramid (python/lucas_kanade_pyramidal.py:46-59) accumulates with fused
+ * multiply-adds, 17 instead of 25 fp64 operations per blurred value on a kernel the fp64 pipe binds.  Intermediates
+ * differ from SciPy's by a few 1e-16 relative before they are rounded to float32 where SciPy rounds, so a pyramid value
+ * differs from the reference's only where the fp64 value lies that close to a float32 rounding boundary (about one in
+ * 10^7, by one ulp); coarse-to-fine LK then amplifies such a difference locally.  Measured on the 13 verification
+ * patterns (tests/test_gpu_round3.py, profiles/): mean EPE against the reference far below the 1e-4 bar.  Affects
+ * oflk_plan_pyramidal / _u8 only; exit-decision flags and oflk_plan_resolve_uncertain keep their meaning relative to
+ * the plan's own pyramid. */
+#define OFLK_ARITH_EXACT 0
+#define OFLK_ARITH_CONTRACTED 1
+int oflk_plan_set_arithmetic(oflk_plan *plan, int mode);
+
 /* Per-kernel timing with HIP events on the launch stream.  While enabled, every
  * kernel launch of the plan is bracketed by an event pair; oflk_plan_kernel_times
  * synchronises, accumulates and reports per kernel class.

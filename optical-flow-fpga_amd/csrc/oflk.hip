@@ -189,6 +189,7 @@ struct oflk_plan {
         bool ready = false;
     } exact;
     GaussW gauss;
+    int arith = OFLK_ARITH_EXACT;   // oflk_plan_set_arithmetic
 #ifdef OFLK_STAMPS
     unsigned *stamps = nullptr;      // diagnostic build: per-wave section cycle sums of the last finest-level launch
     size_t stamps_blocks = 0;
@@ -468,8 +469,14 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
         for (int k = 0; k <= 8; k++) a.w[k] = gauss.w[k];
         dim3 grid((wo + kPTW - 1) / kPTW, (ho + kPTH - 1) / kPTH, nimg);
         Prof pr(plan, s, KC_PYR_FUSED);
-        if (extra && extra->u8) hipLaunchKernelGGL(k_pyr_down<unsigned char>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_pyr_down<float>, grid, dim3(256), 0, s, a);
+        const bool fma = plan && plan->arith == OFLK_ARITH_CONTRACTED;   // opt-in; never the default
+        if (extra && extra->u8) {
+            if (fma) hipLaunchKernelGGL((k_pyr_down<unsigned char, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_pyr_down<unsigned char, false>), grid, dim3(256), 0, s, a);
+        } else {
+            if (fma) hipLaunchKernelGGL((k_pyr_down<float, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_pyr_down<float, false>), grid, dim3(256), 0, s, a);
+        }
         HIP_TRY(hipGetLastError());
         return OFLK_OK;
     }
@@ -1116,6 +1123,15 @@ OFLK_API int oflk_plan_read_level_flow(oflk_plan *p, int level, int pair, float 
         u[i] = both[i].x;
         v[i] = both[i].y;
     }
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_plan_set_arithmetic(oflk_plan *p, int mode)
+{
+    if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
+    if (mode != OFLK_ARITH_EXACT && mode != OFLK_ARITH_CONTRACTED)
+        return fail(OFLK_ERR_INVALID, "arithmetic mode must be OFLK_ARITH_EXACT (0) or OFLK_ARITH_CONTRACTED (1), got %d", mode);
+    p->arith = mode;
     return OFLK_OK;
 }
 

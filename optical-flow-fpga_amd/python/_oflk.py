@@ -72,6 +72,7 @@ SIGNATURES = {
     "oflk_pyramidal_last_uncertain": (ctypes.c_int, [ctypes.c_int] * 6 + [_i32p]),
     "oflk_plan_read_log": (ctypes.c_int, [_vp, _f32p, _i32p, _vp]),
     "oflk_plan_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "oflk_plan_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _vp]),
     "oflk_flow_metrics": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "oflk_plan_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
@@ -223,6 +224,10 @@ class Plan:
         check(lib().oflk_plan_metrics(self._h, d_u, d_v, ptr(ut), ptr(vt), y0, y1, x0, x1,
                                       out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), stream))
         return out
+
+    def set_arithmetic(self, mode: int) -> None:
+        """0 = exact (default: the reference's values), 1 = contracted (opt-in: fused multiply-adds in the Gaussian pyramid)."""
+        check(lib().oflk_plan_set_arithmetic(self._h, int(mode)))
 
     def set_profiling(self, enabled) -> None:
         """False/0 off, True/1 every kernel, 2 only the dominant kernel (finest-level LK iteration)."""

@@ -73,3 +73,78 @@ def test_chunked_single_scale_and_ragged_tail(oracle):
         ou, ov = oracle.lucas_kanade_single_scale(a[i], b[i], 5)
         for k in range(i, B, 2):
             assert np.array_equal(u[k], ou) and np.array_equal(v[k], ov), k
+
+
+def test_contracted_arithmetic_is_opt_in_and_close(golden_dir):
+    """OFLK_ARITH_CONTRACTED (fused multiply-adds in the Gaussian pyramid; include/oflk.h): never the default, and on
+    the 13 verification patterns its flow stays within the north star's tolerance of the reference's (mean EPE <= 1e-4;
+    the exact mode's flow IS the reference's, tests/test_gpu_golden.py).  The measured figures go to
+    gpurun_out/contracted_epe.json (copied to profiles/ by the refresh script)."""
+    import json
+    from pathlib import Path
+
+    import torch
+
+    import _oflk
+    from oflk_synth import synth_pair
+
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    names = [k[len("frame_1__"):] for k in z.files if k.startswith("frame_1__")]
+    p = np.stack([z["frame_0"].astype(np.float32)] * len(names))
+    c = np.stack([z[f"frame_1__{n}"].astype(np.float32) for n in names])
+    tp, tc = torch.from_numpy(p).to(dev), torch.from_numpy(c).to(dev)
+    B, H, W = p.shape
+    plan = _oflk.Plan(0, B, H, W, 3, 5, 3)
+    flows = {}
+    for mode in (0, 1, 0):   # exact, contracted, exact again (the switch leaves nothing behind)
+        plan.set_arithmetic(mode)
+        u, v = torch.empty_like(tp), torch.empty_like(tp)
+        plan.pyramidal(tp.data_ptr(), tc.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+        _, runs = plan.read_log(st)
+        torch.cuda.synchronize()
+        flows.setdefault(mode, []).append((u.cpu().numpy(), v.cpu().numpy(), runs.copy()))
+    (u0, v0, r0), (u0b, v0b, r0b) = flows[0]
+    u1, v1, r1 = flows[1][0]
+    assert np.array_equal(u0, u0b) and np.array_equal(v0, v0b)
+    report = {"patterns": {}}
+    for i, n in enumerate(names):
+        epe = np.sqrt((u1[i].astype(np.float64) - u0[i]) ** 2 + (v1[i].astype(np.float64) - v0[i]) ** 2)
+        report["patterns"][n] = {"mean_epe_vs_reference": float(epe.mean()), "max_epe": float(epe.max()),
+                                 "pixels_differing": int(np.count_nonzero(epe)), "iteration_counts_equal": bool((r0[i] == r1[i]).all())}
+        assert epe.mean() <= 1e-4, (n, float(epe.mean()))
+    plan.close()
+    with pytest.raises(ValueError):
+        _oflk.Plan(0, 1, 32, 32, 2, 5, 1).set_arithmetic(7)
+    # the bench workload: what the mode buys and what it changes there
+    Bb, Hb, Wb = 8, 1080, 1920
+    host = [synth_pair(Hb, Wb, i) for i in range(2)]
+    tp = torch.from_numpy(np.stack([host[i % 2][0] for i in range(Bb)])).to(dev)
+    tc = torch.from_numpy(np.stack([host[i % 2][1] for i in range(Bb)])).to(dev)
+    plan = _oflk.Plan(0, Bb, Hb, Wb, 3, 5, 3)
+    out = {}
+    for mode in (0, 1):
+        plan.set_arithmetic(mode)
+        u, v = torch.empty_like(tp), torch.empty_like(tp)
+        for _ in range(2):
+            plan.pyramidal(tp.data_ptr(), tc.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+        plan.set_profiling(1)
+        for _ in range(5):
+            plan.pyramidal(tp.data_ptr(), tc.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+        torch.cuda.synchronize()
+        kt = plan.kernel_times()
+        plan.set_profiling(0)
+        out[mode] = (u.cpu().numpy(), v.cpu().numpy(), 1e3 * kt["pyr_down_fused"]["total_ms"] / kt["pyr_down_fused"]["launches"],
+                     sum(t["total_ms"] for t in kt.values()) / 5)
+    epe = np.sqrt((out[1][0].astype(np.float64) - out[0][0]) ** 2 + (out[1][1].astype(np.float64) - out[0][1]) ** 2)
+    report["bench_1080p_x8"] = {"mean_epe": float(epe.mean()), "max_epe": float(epe.max()), "pixels_differing": int(np.count_nonzero(epe)),
+                                "pixels": int(epe.size), "pyr_down_us_exact": round(out[0][2], 1), "pyr_down_us_contracted": round(out[1][2], 1),
+                                "pyr_down_ratio": round(out[1][2] / out[0][2], 3), "step_ms_exact": round(out[0][3], 3),
+                                "step_ms_contracted": round(out[1][3], 3)}
+    assert epe.mean() <= 1e-4
+    assert out[1][2] <= 0.85 * out[0][2], report["bench_1080p_x8"]
+    plan.close()
+    outp = Path(__file__).resolve().parents[1] / "gpurun_out"
+    outp.mkdir(exist_ok=True)
+    (outp / "contracted_epe.json").write_text(json.dumps(report, indent=1))
