@@ -395,13 +395,18 @@ def main() -> None:
                     "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": bytes_per_launch,
                     "hbm_floor_us": round(bytes_per_launch / HBM_PEAK_GBS / 1e3, 1)}
         if ib:
-            # the instruction-side bounds of the same launch (the kernel's arithmetic is the reference's, op for op)
+            # the instruction-side bounds of the same launch (the kernel's arithmetic is the reference's, op for op):
+            # dynamic instruction counts (SQ counters of a builder-side run) priced with the wall-clock-validated cycle
+            # table (tools/ubench/valu_wall.hip), scaled to this batch size and set against THIS run's launch time
             scale = B / float(ib["pairs"])   # the counters were taken on a launch of ib["pairs"] pairs; instructions are per pair
             for k in ("valu_pipe", "issue_cadence"):
                 roofline[k] = {"bound": k, "floor_us": round(ib[k]["floor_us"] * scale, 1),
                                "frac": round(ib[k]["floor_us"] * scale / (avg_ms * 1e3), 4)}
-            roofline["binding"] = ("none saturated: latency-bound at 4 waves per SIMD (wave state shares "
-                                   f"{ib.get('wave_state_shares')}); see DESIGN.md section 5")
+            roofline["binding"] = (f"vector ALU: the launch's {ib['wave_instructions_per_launch']['valu'] * scale:.3g} VALU wave-instructions need "
+                                   f"{roofline['valu_pipe']['frac']:.2f} of its time at their saturated rates ({ib.get('price_classes_cycles')} SIMD cycles per "
+                                   "instruction by class, checked against wall-clock); the HBM stream needs "
+                                   f"{roofline['frac']:.2f} (0.73 of the peak is what a 2:1 read:write stream reaches on this chip). The arithmetic is the "
+                                   "reference's op for op (fp64 warp, NumPy-order sums, IEEE divisions), so the 0.70-of-HBM target is out of reach at EPE = 0; DESIGN.md section 5")
             roofline["issue_bounds_source"] = (f"profiles/{ib['_file']} (tools/issue_bounds.py; SQ counters of a {ib['pairs']}-pair "
                                                f"launch scaled to {B} pairs)")
     roofline_pyr = None
@@ -415,6 +420,12 @@ def main() -> None:
                         "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
                         "us_per_call": round(per_call_ms * 1e3, 1), "algorithmic_bytes_per_call": pyr_bytes,
                         "note": "bound by SciPy's fp64 arithmetic (25 fp64 operations per blurred pixel and axis), not by HBM"}
+        ibp = (profile_file("issue_bounds", B, (H, W), any_pairs=True) or {}).get("pyr_down")
+        if ibp and "valu_pipe" in ibp:
+            # the finest pyramid launch alone: its vector-ALU floor against its own duration in the builder-side counter run
+            roofline_pyr["valu_pipe"] = {"bound": "valu_pipe", "frac_of_launch": ibp["valu_pipe"]["frac"],
+                                         "mean_cycles_per_valu_instruction": ibp["mean_saturated_cycles_per_valu_instruction"],
+                                         "note": "fp64 instructions issue at 4.15 SIMD cycles each (wall-clock-validated); this kernel is at its vector-ALU floor"}
     # whole-call view: algorithmic bytes of the full pyramidal call over step time
     step_bytes = sum(algorithmic_bytes_per_pair(dims, L, runs[b])["total"] for b in range(B))
     whole = {"algorithmic_bytes_per_step": step_bytes,
@@ -423,6 +434,32 @@ def main() -> None:
     kernels = {k: {"avg_us": round(1e3 * t["total_ms"] / t["launches"], 2), "launches": t["launches"],
                    "share": round(t["total_ms"] / max(sum(x["total_ms"] for x in ktimes.values()), 1e-12), 4)}
                for k, t in ktimes.items() if t["launches"]}
+
+    # ---- the opt-in contracted arithmetic (fused multiply-adds in the Gaussian pyramid; include/oflk.h): informational,
+    # never `value` -- what it buys on this workload and how many flow values it changes against the exact result ----
+    contracted = None
+    if rank == 0 and world == 1 and L > 1:
+        u_ex, v_ex = u.clone(), v.clone()
+        plan.set_arithmetic(1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        nrep = max(3, min(args.steps, 10))
+        for _ in range(nrep):
+            step()
+        torch.cuda.synchronize()
+        c1 = time.perf_counter()
+        plan.set_arithmetic(0)
+        differing = int(((u != u_ex) | (v != v_ex)).sum().item())
+        d2 = (u.double() - u_ex.double()) ** 2 + (v.double() - v_ex.double()) ** 2
+        contracted = {"value": round(nrep * B * H * W / (c1 - c0) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(1e3 * (c1 - c0) / nrep, 4),
+                      "flow_values_differing_from_exact": differing, "of": int(2 * u.numel()),
+                      "mean_epe_vs_exact": float(d2.sqrt().mean().item()),
+                      "note": "oflk_plan_set_arithmetic(OFLK_ARITH_CONTRACTED): opt-in, not the metric's value"}
+        del u_ex, v_ex, d2
+        step()   # leave the exact result in u, v
+        torch.cuda.synchronize()
 
     # ---- one pair per call (BASELINE config 3 read literally): latency-bound, informational ----
     one_pair = None
@@ -498,6 +535,7 @@ def main() -> None:
             "whole_call": whole,
             "kernels": kernels,
             "job_stats": job_stats,
+            "contracted_arithmetic": contracted,
             "one_pair_per_call": one_pair,
             "cpu_baseline": cpu,
             "epe_vs_reference": parity,

@@ -7,14 +7,16 @@ bounds on the instruction side, both derived from measurements:
   valu_pipe    the vector ALU of a SIMD is occupied  sum_i n_i * c_i  cycles per wave and tile, with
                n_i the wave-instructions of class i (dynamic SQ_INSTS_VALU of the launch, split by the
                static opcode mix of the kernel's ISA) and c_i the saturated SIMD cycles per
-               wave-instruction of that class (tools/ubench/valu_cycles.hip, column w8)
+               wave-instruction of that class, checked against wall-clock (tools/ubench/valu_wall.hip:
+               2.4 for plain fp32 / integer add / logic / move, 4.15 for everything else, 8.1 for v_rcp_f32;
+               round 2's table, from per-wave s_memtime deltas over an assumed occupancy, was 2.5x too low)
   issue_cadence  one wave issues at most one instruction per ~5 cycles (same microbenchmark, column w1:
                5.0-5.6 cycles for every VALU class), so a SIMD holding W waves retires at most W/5
                instructions per cycle; all instruction types of the launch count
 
 Inputs: a directory written by tools/pmc_sq.sh (rocprofv3 --pmc passes over tools/kbench.py), the ISA
-from `make -C optical-flow-fpga_amd/csrc asm`, and profiles/<tag>_valu_cycles.txt.
-Usage: python3 tools/issue_bounds.py gpurun_out/pmc_<tag> profiles/<tag>_valu_cycles.txt profiles/<tag>_issue_bounds.json
+from `make -C optical-flow-fpga_amd/csrc asm`, and profiles/<tag>_valu_wall.txt.
+Usage: python3 tools/issue_bounds.py gpurun_out/pmc_<tag> profiles/<tag>_valu_wall.txt profiles/<tag>_issue_bounds.json
 """
 import collections
 import csv
@@ -32,48 +34,26 @@ CADENCE = 5.0
 
 
 def cycle_table(path):
+    """wall-clock-validated table (tools/ubench/valu_wall.hip): SIMD cycles per wave64 instruction at saturation (w8 rows)"""
     t = {}
     for line in open(path):
-        m = re.match(r"(\S+(?: \S+)*?)\s+w1:\s*([\d.]+)\s+w2:\s*([\d.]+)\s+w4:\s*([\d.]+)\s+w8:\s*([\d.]+)", line)
+        m = re.match(r"(\S.*?)\s+w8\s+wall.*?cyc/SIMD\s+([\d.]+)", line)
         if m:
-            t[m.group(1)] = {"w1": float(m.group(2)), "w4": float(m.group(4)), "w8": float(m.group(5))}
+            t[m.group(1).strip()] = float(m.group(2))
     return t
 
 
-def op_class(op, tbl):
-    """saturated SIMD cycles per wave-instruction of an opcode, from the measured table"""
-    base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
-    w8 = lambda k: tbl[k]["w8"]
-    if "f64" in base and base.startswith("v_cvt"):
-        return w8("v_cvt_f64_f32")
-    if base == "v_floor_f64":
-        return w8("v_floor_f64")
-    if base.endswith("_u64") or base.endswith("_i64"):
-        return w8("v_cmp_le_u64") if base.startswith("v_cmp") else w8("v_add_f64")
-    if "f64" in base or base.startswith("v_pk_") and "f32" in base or base == "v_mov_b64":
-        return w8("v_add_f64")
-    if base == "v_rcp_f32":
-        return w8("v_rcp_f32")
-    if base == "v_div_scale_f32":
-        return w8("v_div_scale_f32")
-    if base in ("v_div_fmas_f32", "v_div_fixup_f32"):
-        return w8("v_div_fmas_f32")
-    if op.endswith("_dpp"):
-        return w8("v_mov_b32_dpp")
-    if base in ("v_fma_f32", "v_fmac_f32"):
-        return w8("v_fma_f32")
-    if base in ("v_mul_u32_u24", "v_mul_i32_i24", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte1", "v_cvt_f32_ubyte2", "v_cvt_f32_ubyte3"):
-        return w8("v_mul_u32_u24")
-    if base in ("v_mad_u32_u24", "v_mad_i32_i24", "v_med3_i32", "v_lshl_add_u32", "v_add_lshl_u32", "v_add3_u32", "v_lshl_or_b32",
-                "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mad_u64_u32", "v_cndmask_b32", "v_bfe_u32", "v_and_or_b32",
-                "v_xad_u32", "v_readfirstlane_b32", "v_readlane_b32", "v_writelane_b32") or base.startswith("v_cmp"):
-        return w8("v_mad_u32_u24")
-    return w8("v_add_f32")   # plain VOP1/VOP2: add, mul, sub, mov, shifts, min/max, logic
+def price_classes(tbl):
+    """three price classes: plain fp32 / integer add / logic / move; everything else; the transcendental unit"""
+    return {"fast": tbl["v_add_f32"], "slow": tbl["v_add_f64"], "rcp": tbl["v_rcp_f32"]}
 
 
-def static_mix(asm_path, tbl):
+def static_mix(asm_path, kernel, prices):
+    sys.path.insert(0, str(ROOT / "tools"))
+    import asm_cost
+
     lines = open(asm_path).read().split("\n")
-    st = [i for i, l in enumerate(lines) if l.startswith(KERNEL + ":")][0]
+    st = [i for i, l in enumerate(lines) if l.startswith(kernel + ":")][0]
     en = [i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end")][0]
     cnt = collections.Counter()
     for l in lines[st + 1:en]:
@@ -81,20 +61,20 @@ def static_mix(asm_path, tbl):
         if l.startswith("v_"):
             cnt[l.split()[0]] += 1
     tot = sum(cnt.values())
-    mean_cost = sum(n * op_class(op, tbl) for op, n in cnt.items()) / tot
-    return tot, mean_cost, cnt
+    cls = {asm_cost.C_FAST: "fast", asm_cost.C_SLOW: "slow", asm_cost.C_RCP: "rcp"}
+    by = collections.Counter()
+    for op, n in cnt.items():
+        by[cls[asm_cost.cost(op)]] += n
+    mean_cost = sum(by[k] * prices[k] for k in by) / tot
+    return tot, mean_cost, {k: by[k] / tot for k in by}
 
 
-def main():
-    pmc_dir, table_path, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
-    tbl = cycle_table(table_path)
-    asm = ROOT / "optical-flow-fpga_amd" / "csrc" / "oflk_gfx950.s"
-    n_static, mean_cost, cnt = static_mix(asm, tbl)
+def kernel_bounds(pmc_dir, match, kernel_sym, asm, prices, hbm_bytes_per_px=None):
     rows = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(dict)
     for f in glob.glob(pmc_dir + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_lkw<2, 1, true" not in r["Kernel_Name"]:
+            if match not in r["Kernel_Name"]:
                 continue
             g = int(r["Grid_Size"])
             rows[g][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -103,27 +83,40 @@ def main():
     c = {k: sum(v) / len(v) for k, v in rows[big].items()}
     us = sum(dur[big].values()) / len(dur[big])
     clock_ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3)          # sum over 8 XCDs / wall
+    n_static, mean_cost, shares = static_mix(asm, kernel_sym, prices)
     valu = c["SQ_INSTS_VALU"]
     total = valu + c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_LDS", 0) + c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0)
     pipe_cycles = valu * mean_cost / N_SIMD
     cadence_cycles = total * CADENCE / (N_SIMD * WAVES_PER_SIMD)
-    res = {
-        "kernel": "k_lkw<2, MODE_ITER, true> finest level, 32 x 1920x1080 (tools/kbench.py under rocprofv3 --pmc)",
-        "pairs": 32, "shape": [1080, 1920],
+    return {
         "launch_us_under_pmc": round(us, 1), "clock_GHz": round(clock_ghz, 3),
         "wave_instructions_per_launch": {"valu": valu, "salu": c.get("SQ_INSTS_SALU"), "lds": c.get("SQ_INSTS_LDS"),
                                          "vmem_rd": c.get("SQ_INSTS_VMEM_RD"), "vmem_wr": c.get("SQ_INSTS_VMEM_WR"), "all": total},
-        "static_valu_instructions": n_static, "mean_saturated_cycles_per_valu_instruction": round(mean_cost, 3),
+        "static_valu_instructions": n_static, "static_valu_class_shares": {k: round(v, 3) for k, v in shares.items()},
+        "mean_saturated_cycles_per_valu_instruction": round(mean_cost, 3),
         "valu_pipe": {"floor_us": round(pipe_cycles / clock_ghz / 1e3, 1), "frac": round(pipe_cycles / clock_ghz / 1e3 / us, 3),
-                      "meaning": "vector-ALU occupancy of the launch's instruction mix at saturated per-instruction rates"},
+                      "meaning": "vector-ALU time of the launch's instructions at the saturated, wall-clock-validated rate of their class"},
         "issue_cadence": {"floor_us": round(cadence_cycles / clock_ghz / 1e3, 1),
                           "frac": round(cadence_cycles / clock_ghz / 1e3 / us, 3), "waves_per_simd": WAVES_PER_SIMD,
                           "cycles_per_instruction_per_wave": CADENCE,
-                          "meaning": "one wave issues <= 1 instruction per ~5 cycles; 4 resident waves per SIMD (127 VGPRs, 38 KB LDS per block)"},
+                          "meaning": "one wave issues <= 1 instruction per ~5 cycles; 4 resident waves per SIMD"},
         "wave_state_shares": {k: round(c[k] / c["SQ_WAVE_CYCLES"], 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
                               if k in c and "SQ_WAVE_CYCLES" in c},
-        "sources": [str(Path(pmc_dir).name), str(Path(table_path).name), "oflk_gfx950.s (make asm)"],
     }
+
+
+def main():
+    pmc_dir, table_path, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+    prices = price_classes(cycle_table(table_path))
+    asm = ROOT / "optical-flow-fpga_amd" / "csrc" / "oflk_gfx950.s"
+    res = kernel_bounds(pmc_dir, "k_lkw<2, 1, true", KERNEL, asm, prices)
+    res = dict({"kernel": "k_lkw<2, MODE_ITER, true> finest level, 32 x 1920x1080 (tools/kbench.py under rocprofv3 --pmc)",
+                "pairs": 32, "shape": [1080, 1920], "price_classes_cycles": prices}, **res)
+    try:
+        res["pyr_down"] = kernel_bounds(pmc_dir, "k_pyr_down<float", "_ZN4oflk10k_pyr_downIfLb0EEEvNS_7PyrArgsE", asm, prices)
+    except Exception as e:   # counters of that kernel missing
+        res["pyr_down"] = {"error": str(e)}
+    res["sources"] = [str(Path(pmc_dir).name), str(Path(table_path).name), "oflk_gfx950.s (make asm)", "tools/asm_cost.py (opcode classes)"]
     Path(out_path).write_text(json.dumps(res, indent=1))
     print(json.dumps(res))
 

@@ -39,8 +39,13 @@ PY
 bash tools/pmc_sq.sh $TAG > gpurun_out/sq_$TAG.log 2>&1
 cp gpurun_out/pmc_$TAG/summary.txt profiles/${TAG}_sq_counters.txt
 # 5. instruction-side bounds of the dominant kernel (needs the ISA: make asm) -> profiles/<tag>_issue_bounds.json
-./tools/ubench/valu_cycles > profiles/${TAG}_valu_cycles.txt 2>&1 || true
-python3 tools/issue_bounds.py gpurun_out/pmc_$TAG profiles/${TAG}_valu_cycles.txt profiles/${TAG}_issue_bounds.json > gpurun_out/issue_$TAG.log 2>&1 || cat gpurun_out/issue_$TAG.log
+# (vector-ALU cycles per instruction checked against wall-clock, with a census of where the waves ran)
+[ -x tools/ubench/valu_wall ] && timeout -k 10 300 ./tools/ubench/valu_wall > profiles/${TAG}_valu_wall.txt 2>&1 || true
+python3 tools/issue_bounds.py gpurun_out/pmc_$TAG profiles/${TAG}_valu_wall.txt profiles/${TAG}_issue_bounds.json > gpurun_out/issue_$TAG.log 2>&1 || cat gpurun_out/issue_$TAG.log
+# 5b. what the SQ "VALU busy" counters mean in cycles (same counters over kernels of known occupancy), and which pipe a
+#     partner kernel on a second stream takes from the step
+bash tools/pmc_calib.sh ${TAG}_calib > gpurun_out/calib_$TAG.log 2>&1 && cp gpurun_out/pmc_${TAG}_calib/summary.txt profiles/${TAG}_sq_counter_calibration.txt || true
+[ -f tools/ubench/libspin.so ] && timeout -k 10 400 python3 tools/corun.py --out profiles/${TAG}_corun.json > gpurun_out/corun_$TAG.log 2>&1 || true
 # 6. in-kernel timeline of the same launch (diagnostic build)                  -> profiles/<tag>_stamps_timeline.{json,txt}
 if [ -f tools/liboflk_stamps.so ]; then
   OFLK_LIB=tools/liboflk_stamps.so timeout -k 10 200 python3 tools/stamps.py profiles/${TAG}_stamps_timeline.json > profiles/${TAG}_stamps_timeline.txt 2>&1 || true
@@ -55,6 +60,8 @@ bash tools/pmc_fp16.sh $TAG > gpurun_out/pmc_fp16_$TAG.log 2>&1 && cp gpurun_out
 python3 tools/hbm_probe.py > profiles/${TAG}_hbm_probe.txt 2>&1 || true
 [ -x tools/ubench/rowwalk ] && timeout -k 10 120 tools/ubench/rowwalk 76 > profiles/${TAG}_rowwalk.txt 2>&1 || true
 python3 -m pytest tests/test_gpu_fp16.py -q > gpurun_out/fp16_tests_$TAG.log 2>&1 && cp gpurun_out/fp16_epe.json profiles/${TAG}_fp16_epe.json || true
+python3 -m pytest tests/test_gpu_round3.py -q -k contracted > gpurun_out/contracted_tests_$TAG.log 2>&1 && cp gpurun_out/contracted_epe.json profiles/${TAG}_contracted_epe.json || true
+python3 tools/host_latency.py > profiles/${TAG}_host_latency.txt 2>&1 && python3 tools/host_latency.py batch >> profiles/${TAG}_host_latency.txt 2>&1 || true
 # 7. every BASELINE config that fits one GPU, and BASELINE configs[3] as one job on this GPU
 python3 tools/measure_configs.py profiles/${TAG}_configs.json > gpurun_out/cfg_$TAG.log 2>&1 || tail -3 gpurun_out/cfg_$TAG.log
 python3 bench.py --config 4k64 --steps 5 --warmup 1 --no-one-pair > gpurun_out/bench_4k64_$TAG.log 2>&1 || tail -3 gpurun_out/bench_4k64_$TAG.log
