@@ -10,10 +10,10 @@ test:             ## CPU suite: oracle vs reference golden vectors, harness, C-A
 test-gpu:         ## on an MI355X: HIP vs oracle / reference digests
 	$(PY) -m pytest tests -x -q -m gpu
 
-bench:            ## one JSON line (32 pairs of 1080p per step, 3-level pyramidal)
+bench:            ## one JSON line (128 pairs of 1080p per step, 3-level pyramidal)
 	$(PY) bench.py
 
 profiles:         ## regenerate profiles/<tag>_* on the GPU box
-	bash tools/refresh_profiles.sh r02
+	bash tools/refresh_profiles.sh r03
 
 .PHONY: build test test-gpu bench profiles
