@@ -22,9 +22,9 @@ sys.path.insert(0, str(ROOT / "optical-flow-fpga_amd" / "python"))
 
 # section = interval ENDING at stamp i (stamps 1 and 2 are compiled out: they cost 17 VGPRs)
 SECTION = {
-    3: "stage 1a: carry->LDS, coalesced loads (prev,u,v), wait, taps of 5 cells, gathers, wait, fp64 sums",
-    4: "stage 1b: taps of the remaining cells, gathers issued (no wait inside)",
-    5: "stage 1c: wait for those gathers, fp64 sums",
+    3: "stage 1a: carry->LDS, coalesced loads (prev,u,v), wait, taps, gathers of the first batch (a continuing tile: all 7 cells), wait, fp64 sums",
+    4: "stage 1b: taps of the second batch, gathers issued (first tile of a segment only: 9 cells = 5 + 4)",
+    5: "stage 1c: wait for those gathers, fp64 sums (first tile of a segment only)",
     6: "stage 1d: avg / It -> LDS",
     7: "barrier 1",
     8: "stage 2: Sobel from LDS (+ carry rows)",
@@ -88,6 +88,8 @@ def main():
                             sums[0] += (int(s[0]) - int(raw[b, w, t - 1, 14])) & 0xffffffff
                     else:
                         d = (int(s[i]) - int(prev_t)) & 0xffffffff
+                        if d > 1000000:   # a stamp this tile did not pass (a continuing tile has ONE gather batch: no 4 / 5)
+                            continue
                         if t == 0:
                             first_tile[i] += d
                         else:

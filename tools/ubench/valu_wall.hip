@@ -55,6 +55,8 @@
 #define I_CND_SELF(i) "v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
 #define I_CMP_CND(i) "v_cmp_gt_f32 vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %8, %9, vcc\n"
 #define I_CMP_F32(i) "v_cmp_gt_f32 vcc, %" #i ", %8\n"
+#define I_CMP_4CND(i) "v_cmp_gt_f32 vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %8, %9, vcc\nv_cndmask_b32 %" #i ", %9, %" #i ", vcc\nv_cndmask_b32 %" #i ", %8, %" #i ", vcc\nv_cndmask_b32 %" #i ", %9, %" #i ", vcc\n"
+#define I_CMP_4CND64(i) "v_cmp_gt_f32 vcc, %" #i ", %8\nv_cndmask_b32_e64 %" #i ", %8, %9, vcc\nv_cndmask_b32_e64 %" #i ", %9, %" #i ", vcc\nv_cndmask_b32_e64 %" #i ", %8, %" #i ", vcc\nv_cndmask_b32_e64 %" #i ", %9, %" #i ", vcc\n"
 #define I_CMP_SGPR(i) "v_cmp_gt_f32_e64 %8, %" #i ", %9\n"
 #define I_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
 #define I_FMAC(i) "v_fmac_f32 %" #i ", %8, %9\n"
@@ -79,7 +81,7 @@
 enum { K_ADD_F32, K_FMA_F32, K_MUL_F32, K_ADD_U32, K_CNDMASK, K_ADD_DPP, K_ADD_WSHR, K_ADD_F64, K_MUL_F64, K_FMA_F64,
        K_PK_ADD_F32, K_PK_FMA_F32, K_CVT_F64_F32, K_CVT_F32_F64, K_RCP, K_FLOOR_F64, K_MIX,
        K_CND_SGPR, K_CND_ZERO, K_CND_SELF, K_CMP_CND, K_CMP_F32, K_CMP_SGPR, K_AND, K_FMAC, K_MED3, K_MAD24, K_MUL24, K_MUL_LO, K_ADD_LSHL, K_LSHL,
-       K_DIV_SCALE, K_DIV_FMAS, K_DIV_FIXUP, K_MIN_F64, K_CMP_U64, K_CVT_F64_I32, K_CVT_I32_F64, K_MOV, K_MOV_DPP, K_FLOOR_F32, K_CVT_F32_U8, K_COUNT };
+       K_DIV_SCALE, K_DIV_FMAS, K_DIV_FIXUP, K_MIN_F64, K_CMP_U64, K_CVT_F64_I32, K_CVT_I32_F64, K_MOV, K_MOV_DPP, K_FLOOR_F32, K_CVT_F32_U8, K_CMP_4CND, K_CMP_4CND64, K_COUNT };
 struct Kind { const char *name; double flops; };   // flops per lane and instruction
 const Kind kKinds[K_COUNT] = {
     {"v_add_f32", 1}, {"v_fma_f32", 2}, {"v_mul_f32", 1}, {"v_add_u32", 1}, {"v_cndmask_b32 (vcc)", 1},
@@ -90,7 +92,7 @@ const Kind kKinds[K_COUNT] = {
     {"v_cmp_gt_f32 vcc", 1}, {"v_cmp_gt_f32 sgpr", 1}, {"v_and_b32", 1}, {"v_fmac_f32", 2}, {"v_med3_i32", 1}, {"v_mad_i32_i24", 1}, {"v_mul_i32_i24", 1},
     {"v_mul_lo_u32", 1}, {"v_add_lshl_u32", 1}, {"v_lshlrev_b32", 1}, {"v_div_scale_f32", 1}, {"v_div_fmas_f32", 1}, {"v_div_fixup_f32", 1},
     {"v_min_f64", 1}, {"v_cmp_ge_u64", 1}, {"v_cvt_f64_i32", 1}, {"v_cvt_i32_f64", 1}, {"v_mov_b32", 1}, {"v_mov_b32_dpp row_shr:1", 1},
-    {"v_floor_f32", 1}, {"v_cvt_f32_ubyte0", 1}};
+    {"v_floor_f32", 1}, {"v_cvt_f32_ubyte0", 1}, {"v_cmp + 4 v_cndmask_e32 (5 instr)", 1}, {"v_cmp + 4 v_cndmask_e64 vcc (5 instr)", 1}};
 
 constexpr int kWordsPerWave = 8;
 
@@ -149,6 +151,8 @@ __global__ void k(unsigned *out, int iters, float seed)
         if (KIND == K_FLOOR_F32) { R4(OP32(I_FLOOR_F32)) }
         if (KIND == K_CVT_F32_U8) { R4(OP32(I_CVT_F32_U8)) }
         if (KIND == K_CMP_SGPR) { R4(OP32SW(I_CMP_SGPR)) }
+        if (KIND == K_CMP_4CND) { R4(OP32(I_CMP_4CND)) }
+        if (KIND == K_CMP_4CND64) { R4(OP32(I_CMP_4CND64)) }
         if (KIND == K_MIX) { OP32(I_ADD_F32) OP32(I_ADD_F32) OP32(I_ADD_F32) OP64(I_ADD_F64) }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -215,7 +219,7 @@ void run(unsigned *d_out, int max_waves)
         std::vector<int> occ;
         for (auto &kv : per_simd) occ.push_back(kv.second);
         std::sort(occ.begin(), occ.end());
-        const double n_instr = (double)nw * iters * 32.0 * (KIND == K_CMP_CND ? 2.0 : 1.0);
+        const double n_instr = (double)nw * iters * 32.0 * (KIND == K_CMP_CND ? 2.0 : (KIND == K_CMP_4CND || KIND == K_CMP_4CND64) ? 5.0 : 1.0);
         const double wall_s = ms * 1e-3;
         const double simds = (double)per_simd.size();
         printf("%-28s w%d  wall %8.1f us  %7.2f Ginstr/s  clock %.2f GHz  cyc/SIMD %5.2f  per-wave cadence %5.2f cyc  %6.1f TFLOP/s  "
