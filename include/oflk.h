@@ -39,7 +39,8 @@ extern "C" {
 #define OFLK_ERR_NOMEM (-5)       /* device or host allocation failed */
 
 #define OFLK_MAX_LEVELS 16
-#define OFLK_MAX_WINDOW 11 /* largest window_size with a compiled kernel (3x3 ... 11x11; even sizes round down like the reference) */
+#define OFLK_MAX_WINDOW 45 /* largest window_size (45 x 45 = 2025 products; even sizes round down like the reference) */
+#define OFLK_MAX_TILED_WINDOW 11 /* 3x3 ... 11x11 run the tiled kernels; every other size the generic one-thread-per-pixel kernel */
 
 /* ---- library ------------------------------------------------------------ */
 const char *oflk_version(void);
@@ -163,10 +164,12 @@ typedef struct oflk_plan oflk_plan;
 /* Allocate the workspace (pyramids, flow ping-pong buffers, reduction scratch)
  * for B pairs of H x W on `device`.  levels = 1 and iters = 0 gives a plan that
  * can only run oflk_plan_single_scale.
- *   window_size : 2 ... 11.  Kernels exist for the 3x3 ... 11x11 windows; like the reference
- *                 (lucas_kanade_core.py:104, :110) a size w uses the (2*(w/2)+1)^2 window, so 4 and 5
- *                 both mean 5x5.  Sizes 1 and > 11, which the reference accepts, return
- *                 OFLK_ERR_UNSUPPORTED.
+ *   window_size : 1 ... 45.  Like the reference (lucas_kanade_core.py:104, :110) a size w uses the (2*(w/2)+1)^2
+ *                 window, so 4 and 5 both mean 5x5.  3x3 ... 11x11 (sizes 2 ... 11) run the tiled kernels.  Every other
+ *                 size -- 1x1, 13x13 ... 45x45, where np.sum's pairwise order splits into blocks -- runs a generic
+ *                 kernel (one thread per output pixel, the sums in NumPy's order for any length; a pyramidal pass
+ *                 then runs pair by pair, unfused, with the exit test on the host): the reference's values, slowly.
+ *                 Sizes above 45 return OFLK_ERR_UNSUPPORTED; the fp16 mode exists for 2 ... 11 only.
  *   A plan is single-stream: it owns one per-call state block, so at most ONE pass of a plan may be
  *   in flight at a time (enqueue passes of one plan on one stream, or synchronise between streams).
  *   Device pointers: when W % 4 == 0 the kernels move 16 bytes per lane and want every plane

@@ -145,13 +145,16 @@ int level_dims(int H, int W, int levels, double scale, int *dims)
     return OFLK_OK;
 }
 
+// windows with a tiled kernel (3x3 ... 11x11); every other admissible size runs the generic one-thread-per-pixel kernel
+inline bool tiled_window(int hw) { return hw >= 1 && hw <= 5; }
+
 int window_hw(int window_size, int *hw)
 {
     if (window_size < 1) return fail(OFLK_ERR_INVALID, "window_size must be >= 1");
     int h = window_size / 2;  // even sizes round down, lucas_kanade_core.py:104
-    if (h < 1 || h > 5)
-        return fail(OFLK_ERR_UNSUPPORTED,
-                    "window_size %d not built (kernels exist for 3x3 ... 11x11 windows)", window_size);
+    if (window_size > OFLK_MAX_WINDOW || pairwise_depth((2 * h + 1) * (2 * h + 1)) > kGenericDepth)
+        return fail(OFLK_ERR_UNSUPPORTED, "window_size %d not built (windows of up to %d x %d)", window_size, OFLK_MAX_WINDOW,
+                    OFLK_MAX_WINDOW);
     *hw = h;
     return OFLK_OK;
 }
@@ -289,6 +292,22 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         hipLaunchKernelGGL((k_lk_degenerate<MODE>), dim3(nb, (unsigned)B), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         return OFLK_OK;
+    }
+    if (!tiled_window(hw)) {
+        // 1x1, 13x13 and larger windows: one thread per output pixel, np.sum's pairwise order for any length
+        if constexpr (MODE == MODE_ITER) {
+            return fail(OFLK_ERR_UNSUPPORTED, "the fused iteration has no kernel for half window %d", hw);   // (plans of such windows run unfused)
+        } else {
+            const dim3 grid((a.W + 63) / 64, (a.H + 3) / 4, (unsigned)B);
+            if constexpr (MODE == MODE_SINGLE) {
+                if (u8) hipLaunchKernelGGL((k_lk_generic<MODE_SINGLE, unsigned char>), grid, dim3(256), 0, s, a, hw);
+                else hipLaunchKernelGGL((k_lk_generic<MODE_SINGLE, float>), grid, dim3(256), 0, s, a, hw);
+            } else {
+                hipLaunchKernelGGL((k_lk_generic<MODE_GRADS, float>), grid, dim3(256), 0, s, a, hw);
+            }
+            HIP_TRY(hipGetLastError());
+            return OFLK_OK;
+        }
     }
     constexpr int cap_env = 8;   // tiles per chained block at most (12 / 16 were measured: no change)
     const long resident = 1024;  // 256 CUs x 4 blocks
@@ -570,7 +589,7 @@ void plan_free(oflk_plan *p)
 // =============================================================================
 // library
 // =============================================================================
-OFLK_API const char *oflk_version(void) { return "oflk 0.2.0 (gfx950)"; }
+OFLK_API const char *oflk_version(void) { return "oflk 0.3.0 (gfx950)"; }
 
 OFLK_API int oflk_device_count(void)
 {
@@ -666,6 +685,7 @@ int plan_single_scale(oflk_plan *p, const void *d_prev, const void *d_curr, bool
     return launch_lk<MODE_SINGLE>(p, s, KC_LK_SINGLE, p->hw, a, p->B, u8);
 }
 int plan_pyramidal(oflk_plan *p, const void *d_prev, const void *d_curr, bool u8, float *d_u, float *d_v, hipStream_t s);
+int resolve_pair(oflk_plan *p, int b, const void *d_prev_in, const void *d_curr_in, bool u8, float *d_u, float *d_v, hipStream_t s);
 }  // namespace
 
 OFLK_API int oflk_plan_single_scale(oflk_plan *p, const float *d_prev, const float *d_curr,
@@ -778,6 +798,15 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
     if (!p->flow[0]) {   // a plan created with levels = 1, iters = 0 (single-scale use) asked for a pyramidal pass after all
         for (int l = 0; l < L; l++)
             if ((rc = dmalloc(&p->flow[l], (size_t)2 * 2 * B * p->npix(l), &p->ws_bytes))) return rc;
+    }
+
+    if (!tiled_window(p->hw)) {
+        // 1x1 / 13x13 and larger windows have no fused iteration kernel: every pair runs the reference's own sequence of
+        // steps with the standalone kernels (resolve_pair: pyramid, warp, generic single-scale LK, flow += d, upsample,
+        // np.mean in NumPy's order, the exit test on the host) -- exact, and as slow as that sounds
+        for (int b = 0; b < B; b++)
+            if ((rc = resolve_pair(p, b, d_prev_in, d_curr_in, u8, d_u, d_v, s))) return rc;
+        return OFLK_OK;
     }
 
     // per-call state (acc, iters_run, log) = 0 and flow = zeros at the coarsest level (:182-184):
@@ -1367,10 +1396,12 @@ int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *cur
     if (tail != C && (rc = host_plan(*c, dev, tail, H, W, Lp, window_size, Kp, &pt))) return rc;
     if (tail != C && (rc = host_plan(*c, dev, C, H, W, Lp, window_size, Kp, &pc))) return rc;   // (the cache may have moved it)
 
-    hipEvent_t ev_in[2], ev_out[2];
+    hipEvent_t ev_in[2] = {nullptr, nullptr};   // a slot's frames have arrived
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
+        if (hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming) != hipSuccess) {
+            if (ev_in[0]) (void)hipEventDestroy(ev_in[0]);
+            return fail(OFLK_ERR_HIP, "hipEventCreate");
+        }
     }
     // hand-over to the D2H thread: chunks [0, computed) are ready to leave, chunks [0, copied) have left
     std::mutex mu;
@@ -1378,7 +1409,8 @@ int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *cur
     int computed = 0, copied = 0, out_rc = OFLK_OK;
     bool stop = false;
     std::string out_msg;
-    std::thread out_thread([&]() {
+    std::thread out_thread;
+    auto out_body = [&]() {
         if (ensure_device(dev)) { std::lock_guard<std::mutex> g(mu); out_rc = OFLK_ERR_HIP; out_msg = t_err; cv.notify_all(); return; }
         for (int k = 0; k < nchunk; k++) {
             {
@@ -1401,7 +1433,13 @@ int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *cur
             copied = k + 1;
             cv.notify_all();
         }
-    });
+    };
+    try {
+        out_thread = std::thread(out_body);
+    } catch (...) {   // no exception leaves the C ABI
+        for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev_in[i]);
+        return fail(OFLK_ERR_HIP, "could not start the D2H thread of a chunked batch");
+    }
     auto finish = [&](int code) {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -1409,10 +1447,7 @@ int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *cur
         }
         cv.notify_all();
         out_thread.join();
-        for (int i = 0; i < 2; i++) {
-            (void)hipEventDestroy(ev_in[i]);
-            (void)hipEventDestroy(ev_out[i]);
-        }
+        for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev_in[i]);
         if (code == OFLK_OK && out_rc != OFLK_OK) return fail(out_rc, "%s", out_msg.c_str());
         return code;
     };
@@ -1439,7 +1474,8 @@ int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *cur
         float *du = c->ring_out[slot][0], *dv = c->ring_out[slot][1];
         rc = single ? plan_single_scale(p, dp, dc, U8, du, dv, c->s_comp) : plan_pyramidal(p, dp, dc, U8, du, dv, c->s_comp);
         if (rc) return finish(rc);
-        // the next chunk's frames travel while this one is computed (its slot's kernels, chunk k-1, were waited for below)
+        // the next chunk's frames travel while this one is computed (the kernels that read its slot, chunk k-1's, are done:
+        // the previous turn of this loop ended by waiting for them)
         if (k + 1 < nchunk && (rc = h2d(k + 1))) return finish(rc);
         if (!single && iters > 0) {
             int n = 0;
@@ -1485,7 +1521,7 @@ int run_batch_on(int dev, const PIXELS *prev, const PIXELS *curr, int B, int H, 
     if ((rc = acquire(dev, &c, lk))) return rc;
     const bool single = levels == 0;
     {
-        // chunks of ~32 MB of flow per plane (two 1080p pairs); worth it from four chunks on
+        // chunks of ~32 MB of flow per plane (four 1080p pairs, one 4K pair); worth it from four chunks on
         const size_t pair_out = (size_t)H * W * sizeof(float);
         const int C = (int)std::max<size_t>(1, ((size_t)32 << 20) / std::max<size_t>(pair_out, 1));
         if (B >= 4 * C && (size_t)B * pair_out >= ((size_t)64 << 20))

@@ -730,6 +730,168 @@ __global__ __launch_bounds__(256) void k_lk_degenerate(LkArgs a)
     // d = 0: nothing to add to the accumulators; the iteration reads as converged
 }
 
+// ---------------------------------------------------------------------------
+// Windows outside 3x3 ... 11x11 (the reference takes any window_size, lucas_kanade_core.py:104-119): one thread per
+// output pixel walks its (2hw+1)^2 window and forms the five sums in np.sum's pairwise order for ANY length
+// (numpy/_core/src/umath/loops_utils.h.src: fewer than 8 values one after the other; up to 128 values in eight
+// interleaved accumulators, the fixed tree, then the tail; beyond that two halves, the first a multiple of 8 long,
+// each summed the same way -- a 13x13 window is 169 products: 80 + 89).  Exact and slow: the tiled kernel's window
+// sums live in registers because their shape is known at compile time; this one is the catch-all.
+// SINGLE evaluates the gradients of every window element from the frames as k_gradients does (same operations).
+// ---------------------------------------------------------------------------
+struct Five {
+    float xx, yy, xy, xt, yt;
+};
+__device__ __forceinline__ Five operator+(Five a, Five b)
+{
+    return Five{a.xx + b.xx, a.yy + b.yy, a.xy + b.xy, a.xt + b.xt, a.yt + b.yt};
+}
+
+template <class ELEM>
+__device__ __forceinline__ Five np_pairwise_leaf(ELEM &elem, int lo, int n, int side)   // n <= 128
+{
+    int r = lo / side, c = lo - r * side;
+    auto next = [&]() {
+        const Five e = elem(r, c);
+        if (++c == side) {
+            c = 0;
+            r++;
+        }
+        return e;
+    };
+    if (n < 8) {
+        Five res{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < n; i++) res = res + next();
+        return res;
+    }
+    Five acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = next();
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = acc[j] + next();
+    }
+    Five res = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; i < n; i++) res = res + next();
+    return res;
+}
+
+// np.sum halves unevenly (the first half is cut down to a multiple of 8), so d levels of halving cover a little less than
+// 128 << d values: 1 808 at d = 4, 3 600 at d = 5.  The host admits windows of up to 45 x 45 = 2 025 products and checks
+// the depth of each (pairwise_depth).
+constexpr int kGenericDepth = 5;
+__host__ __device__ constexpr int pairwise_depth(int n)
+{
+    if (n <= 128) return 0;
+    const int n2 = n / 2 - (n / 2) % 8;
+    const int a = pairwise_depth(n2), b = pairwise_depth(n - n2);
+    return 1 + (a > b ? a : b);
+}
+static_assert(pairwise_depth(45 * 45) <= kGenericDepth && pairwise_depth(169) == 1, "block recursion depth of np.sum");
+
+// np.sum's recursion (two halves, the first a multiple of 8 long, down to blocks of at most 128) walked with an explicit
+// stack, so that the block sum exists once in the code: a frame is (range, stage, the left half's sum).
+template <class ELEM>
+__device__ __forceinline__ Five np_pairwise(ELEM &elem, int n, int side)
+{
+    int f_lo[kGenericDepth + 1], f_n[kGenericDepth + 1], f_stage[kGenericDepth + 1];
+    Five f_left[kGenericDepth + 1];
+    int sp = 0;
+    f_lo[0] = 0;
+    f_n[0] = n;
+    f_stage[0] = 0;
+    Five ret{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    while (sp >= 0) {
+        const int lo = f_lo[sp], len = f_n[sp];
+        if (len <= 128 || sp == kGenericDepth) {
+            ret = np_pairwise_leaf(elem, lo, len, side);
+            sp--;
+            continue;
+        }
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        if (f_stage[sp] == 0) {          // descend into the left half
+            f_stage[sp] = 1;
+            f_lo[sp + 1] = lo;
+            f_n[sp + 1] = n2;
+            f_stage[sp + 1] = 0;
+            sp++;
+        } else if (f_stage[sp] == 1) {   // left half done: keep it, descend into the right half
+            f_left[sp] = ret;
+            f_stage[sp] = 2;
+            f_lo[sp + 1] = lo + n2;
+            f_n[sp + 1] = len - n2;
+            f_stage[sp + 1] = 0;
+            sp++;
+        } else {                         // both done
+            ret = f_left[sp] + ret;
+            sp--;
+        }
+    }
+    return ret;
+}
+
+// grid: (ceil(W / 64), ceil(H / 4), B)
+template <int MODE, class PIX = float>
+__global__ __launch_bounds__(256) void k_lk_generic(LkArgs a, int hw)
+{
+    static_assert(MODE == MODE_SINGLE || MODE == MODE_GRADS, "the iteration is run unfused for these windows");
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int H = a.H, W = a.W;
+    if (x >= W || y >= H) return;
+    const size_t base = (size_t)blockIdx.z * (size_t)H * (size_t)W;
+    const size_t o = base + (size_t)y * W + x;
+    float u = 0.0f, v = 0.0f;
+    if (y >= hw && y < H - hw && x >= hw && x < W - hw) {   // borders stay 0 (lucas_kanade_core.py:101-108)
+        const int side = 2 * hw + 1;
+        auto elem = [&](int r, int c) -> Five {
+            const int gy = y - hw + r, gx = x - hw + c;
+            float ix, iy, it;
+            if constexpr (MODE == MODE_GRADS) {
+                const size_t i = base + (size_t)gy * W + gx;
+                ix = a.prev[i];
+                iy = a.curr[i];
+                it = a.aux[i];
+            } else {
+                const PIX *__restrict__ prev = reinterpret_cast<const PIX *>(a.prev);
+                const PIX *__restrict__ curr = reinterpret_cast<const PIX *>(a.curr);
+                auto avg = [&](int yy, int xx) -> float {   // (prev + curr) / 2 with the "symm" ring, as k_gradients
+                    yy = min(max(yy, 0), H - 1);
+                    xx = min(max(xx, 0), W - 1);
+                    const size_t i = base + (size_t)yy * W + xx;
+                    const float s = (float)prev[i] + (float)curr[i];
+                    return s * 0.5f;
+                };
+                const float a_mm = avg(gy - 1, gx - 1), a_m0 = avg(gy - 1, gx), a_mp = avg(gy - 1, gx + 1);
+                const float a_0m = avg(gy, gx - 1), a_0p = avg(gy, gx + 1);
+                const float a_pm = avg(gy + 1, gx - 1), a_p0 = avg(gy + 1, gx), a_pp = avg(gy + 1, gx + 1);
+                ix = a_pp * -0.125f;
+                ix = fmaf(a_pm, 0.125f, ix);
+                ix = fmaf(a_0p, -0.25f, ix);
+                ix = fmaf(a_0m, 0.25f, ix);
+                ix = fmaf(a_mp, -0.125f, ix);
+                ix = fmaf(a_mm, 0.125f, ix);
+                iy = a_pp * -0.125f;
+                iy = fmaf(a_p0, -0.25f, iy);
+                iy = fmaf(a_pm, -0.125f, iy);
+                iy = fmaf(a_mp, 0.125f, iy);
+                iy = fmaf(a_m0, 0.25f, iy);
+                iy = fmaf(a_mm, 0.125f, iy);
+                const size_t i = base + (size_t)gy * W + gx;
+                it = (float)prev[i] - (float)curr[i];
+            }
+            return Five{ix * ix, iy * iy, ix * iy, ix * it, iy * it};
+        };
+        const Five s = np_pairwise(elem, side * side, side);
+        // np.sum starts from the identity 0
+        lk_solve(0.0f + s.xx, 0.0f + s.yy, 0.0f + s.xy, 0.0f + s.xt, 0.0f + s.yt, u, v);
+    }
+    a.ou[o] = u;
+    a.ov[o] = v;
+}
+
 // does k_lkw<HW, MODE> support walking several tiles per block (vertical chaining)?
 template <int HW, int MODE>
 constexpr bool kLkChain = HW <= 2 && MODE != MODE_GRADS;

@@ -560,20 +560,3 @@ def test_bench_multi_inproc_rehearsal():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["pairs_per_step_job"] == 64
     assert j["config"]["pairs_per_gpu_per_step"] == [32, 32] and j["job_stats"]["mean_abs_u"] > 0
-
-
-@pytest.mark.parametrize("win", [1, 12, 13, 25])
-def test_windows_without_a_kernel_are_refused_loudly(win):
-    """the reference takes any window_size (lucas_kanade_core.py:104-119); kernels exist for 3x3 ... 11x11 (sizes 2 ... 11),
-    every other size returns OFLK_ERR_UNSUPPORTED with the documented message (include/oflk.h), never a wrong flow"""
-    import _oflk
-    import lucas_kanade_core as K
-    import lucas_kanade_pyramidal as P
-
-    a = np.zeros((32, 48), np.float32)
-    for call in (lambda: K.lucas_kanade_single_scale(a, a, win), lambda: P.lucas_kanade_pyramidal(a, a, 2, win, 1),
-                 lambda: _oflk.Plan(0, 1, 32, 48, 1, win, 0)):
-        with pytest.raises(_oflk.OflkError) as e:
-            call()
-        assert e.value.code == _oflk.OFLK_ERR_UNSUPPORTED
-        assert f"window_size {win} not built (kernels exist for 3x3 ... 11x11 windows)" in str(e.value)

@@ -193,3 +193,29 @@ def test_pyramid_other_scale_factors_equal_the_reference(oracle, golden_dir):
         pyr = oracle.build_gaussian_pyramid(z["image"], 3, sf)
         for l, a in enumerate(pyr):
             np.testing.assert_array_equal(a, z[f"sf{sf}_level{l}"])
+
+
+def test_windows_outside_3_to_11_match_the_reference(oracle, golden_dir):
+    """window sizes the reference accepts beyond the tiled kernels' range (1x1; 13x13 and larger, where np.sum's
+    pairwise order splits into blocks): the oracle reproduces the digests made by importing the reference
+    (tests/golden/make_golden_windows.py) -- this pins the generic-window path's checker"""
+    import hashlib
+    import json
+
+    ref = json.loads((golden_dir / "reference_windows.json").read_text())
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    (y0, y1), (x0, x1) = ref["crop"]
+
+    def digest(a):
+        return hashlib.sha256((np.ascontiguousarray(a, np.float32) + np.float32(0.0)).tobytes()).hexdigest()
+
+    for name, e in ref["patterns"].items():
+        p = np.ascontiguousarray(z["frame_0"].astype(np.float32)[y0:y1, x0:x1])
+        c = np.ascontiguousarray(z[f"frame_1__{name}"].astype(np.float32)[y0:y1, x0:x1])
+        for win, d in e["single_scale"].items():
+            u, v = oracle.lucas_kanade_single_scale(p, c, int(win))
+            assert digest(u) == d["u_sha256"] and digest(v) == d["v_sha256"], (name, win)
+            assert int(np.count_nonzero(u)) == d["nonzero_u"]
+        for win, d in e["pyramidal"].items():
+            u, v = oracle.lucas_kanade_pyramidal(p, c, d["levels"], int(win), d["iterations"])
+            assert digest(u) == d["u_sha256"] and digest(v) == d["v_sha256"], (name, win)
