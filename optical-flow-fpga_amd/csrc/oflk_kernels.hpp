@@ -1880,12 +1880,13 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
         constexpr int RS = 12;                       // rows per thread (3 segments cover 34)
         const int col = tid % kPIW, seg = tid / kPIW;
         if (seg < 3) {
+            // the window's rows at a per-thread base plus constants; only the last segment's last rows lie past the
+            // tile (they feed outputs that are not stored) and are clamped
+            constexpr int KSAFE = kPIH - 2 * RS;         // rows k < KSAFE exist for every segment
+            const float *wb = &s_in[seg * RS * kPIW + col];
             float win[RS + 16];
 #pragma unroll
-            for (int k = 0; k < RS + 16; k++) {
-                int r = min(seg * RS + k, kPIH - 1);
-                win[k] = s_in[r * kPIW + col];
-            }
+            for (int k = 0; k < RS + 16; k++) win[k] = k < KSAFE ? wb[k * kPIW] : wb[min(k, kPIH - 1 - seg * RS) * kPIW];
 #pragma unroll
             for (int o = 0; o < RS; o++) {
                 using AccB = double;
@@ -1915,9 +1916,11 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
         static_assert(kPBH * NSEG <= 256, "one thread per (row, segment)");
         const int row = tid % kPBH, seg = tid / kPBH;
         if (seg < NSEG) {
+            constexpr int KSAFE = kPIW - (NSEG - 1) * CS;   // columns k < KSAFE exist for every segment
+            const float *wb = &s_v[row * kPVS + seg * CS];
             float win[CS + 16];
 #pragma unroll
-            for (int k = 0; k < CS + 16; k++) win[k] = s_v[row * kPVS + min(seg * CS + k, kPIW - 1)];
+            for (int k = 0; k < CS + 16; k++) win[k] = k < KSAFE ? wb[k] : wb[min(k, kPIW - 1 - seg * CS)];
 #pragma unroll
             for (int o = 0; o < CS; o++) {
                 using AccC = double;
@@ -1947,7 +1950,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrArgs a)
         if (i >= a.Ho || j >= a.Wo) continue;
         double y = linspace_at(a.ly, i), x = linspace_at(a.lx, j);
         float r = 0.0f;
-        if (!(y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1))) {
+        {   // np.linspace(0, S-1, T) never leaves [0, S-1] (its last point IS S-1): map_coordinates' outside test cannot fire
             double fy = floor(y), fx = floor(x);
             int y0 = (int)fy, x0 = (int)fx;
             double wy0 = 1.0 - (y - fy), wx0 = 1.0 - (x - fx);

@@ -247,7 +247,7 @@ def test_errors_are_loud():
     with pytest.raises(ValueError):
         K_.lucas_kanade_single_scale(a, np.zeros((8, 9), np.float32))
     with pytest.raises(_oflk.OflkError):
-        K_.lucas_kanade_single_scale(a, a, 13)  # window not built -> explicit error, no fallback
+        K_.lucas_kanade_single_scale(a, a, 47)  # window beyond 45x45 -> explicit error, no fallback
     # C ABI argument checks: status code + message, never a crash
     import ctypes
 
