@@ -926,15 +926,15 @@ constexpr bool kLkChain = HW <= 2 && MODE != MODE_GRADS;
 // launch.  site 1 = stage 1 after the coalesced loads are issued, 3 = stage 3 after the window sums; kind 1 = 96
 // v_add_f32, 2 = 96 v_add_f64, 3 = 96 s_mov_b32, 4 = 24 dependent ds_read_b32.  Results stay correct.
 #if defined(OFLK_DIAG) && defined(OFLK_PROBE)
-#define OFLK_X_PROBE OFLK_PROBE
+#define OFLK_PROBE_SITE_KIND OFLK_PROBE
 #else
-#define OFLK_X_PROBE 0
+#define OFLK_PROBE_SITE_KIND 0
 #endif
 template <int SITE>
 __device__ __forceinline__ void probe(const float *lds)
 {
-    if constexpr ((OFLK_X_PROBE >> 8) == SITE) {
-        constexpr int KIND = OFLK_X_PROBE & 255;
+    if constexpr ((OFLK_PROBE_SITE_KIND >> 8) == SITE) {
+        constexpr int KIND = OFLK_PROBE_SITE_KIND & 255;
         if constexpr (KIND == 1) {
             float r[8] = {1, 2, 3, 4, 5, 6, 7, 8};
 #pragma unroll

@@ -85,3 +85,24 @@ def test_product_modules_never_touch_the_oracle():
         if f.suffix in (".py", ".hip", ".hpp", ".cpp", ".h") and f.is_file():
             text = f.read_text()
             assert "oflk_oracle" not in text and "liboflk_oracle" not in text, f
+
+
+def test_product_translation_unit_carries_no_development_switches():
+    """the shipped library reads no environment variable and carries no timing / ablation switches: diagnostic code
+    (in-kernel stamps, sensitivity probes) only exists under -DOFLK_DIAG"""
+    import re
+
+    csrc = ROOT / "optical-flow-fpga_amd" / "csrc"
+    hip = (csrc / "oflk.hip").read_text()
+    hpp = (csrc / "oflk_kernels.hpp").read_text()
+    assert "getenv" not in hip and "getenv" not in hpp
+    for word in ("OFLK_ABLATE", "OFLK_LK16_ABL", "OFLK_LK16_TILED", "OFLK_LK16_COLS", "OFLK_TPB", "OFLK_X_"):
+        assert word not in hip, word
+    for word in ("OFLK_ABLATE", "OFLK_LK16_ABL", "k_lk16s", "k_lk16<"):
+        assert word not in hpp, word
+    # every stamp / probe site is behind the diagnostic build
+    assert re.search(r"#if defined\(OFLK_STAMPS\) && !defined\(OFLK_DIAG\)\s*\n#error", hpp)
+    assert "#if defined(OFLK_DIAG) && defined(OFLK_PROBE)" in hpp
+    mk = (csrc / "Makefile").read_text()
+    default_flags = [l for l in mk.splitlines() if l.startswith("FLAGS")][0]
+    assert "OFLK_DIAG" not in default_flags
