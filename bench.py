@@ -94,30 +94,46 @@ def live_traffic(pairs: int, shape, timeout_s: int = 240) -> dict | None:
     out = {}
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                d = os.path.join(tmp, counter)
-                cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+            # separate passes (the guide: FETCH_SIZE and WRITE_SIZE do not fit one); the third one counts the launch's
+            # vector-ALU wave-instructions for roofline.valu_pipe
+            for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
+                d = os.path.join(tmp, counters[0])
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
                        sys.executable, str(ROOT / "tools" / "kbench.py"), "--pairs", str(pairs), "--height", str(shape[0]),
                        "--width", str(shape[1]), "--reps", "3"]
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                    stderr=subprocess.DEVNULL, timeout=timeout_s)
                 if r.returncode != 0:
+                    if counters[0] == "SQ_INSTS_VALU":
+                        break   # the traffic figure stands without it
                     return None
-                rows = []
-                for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-                    for row in csv.DictReader(open(f)):
-                        if "k_lkw<2, 1" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
-                if not rows:
-                    return None
-                big = max(g for g, _ in rows)   # finest level = largest grid
-                vals = [v for g, v in rows if g == big]
-                out[counter] = (sum(vals) / len(vals), len(vals))
+                for counter in counters:
+                    rows = []
+                    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                        for row in csv.DictReader(open(f)):
+                            if "k_lkw<2, 1" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                                rows.append((int(row["Grid_Size"]), float(row["Counter_Value"]),
+                                             (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+                    if not rows:
+                        if counters[0] == "SQ_INSTS_VALU":
+                            continue
+                        return None
+                    big = max(g for g, _, _ in rows)   # finest level = largest grid
+                    vals = [v for g, v, _ in rows if g == big]
+                    out[counter] = (sum(vals) / len(vals), len(vals), sum(u for g, _, u in rows if g == big) / len(vals))
     except Exception:
         return None
+    if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+        return None
     fetch, write = out["FETCH_SIZE"][0] * 1024 * 2, out["WRITE_SIZE"][0] * 1024
-    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
-            "launches_averaged": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
+    res = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+           "launches_averaged": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
+    if "SQ_INSTS_VALU" in out and "GRBM_GUI_ACTIVE" in out:
+        us = out["SQ_INSTS_VALU"][2]
+        res["valu_wave_instructions_per_launch"] = out["SQ_INSTS_VALU"][0]
+        res["launch_us_under_pmc"] = us
+        res["clock_GHz_under_pmc"] = out["GRBM_GUI_ACTIVE"][0] / 8.0 / (us * 1e3)   # the counter is summed over the 8 XCDs
+    return res
 
 
 def self_launch(argv) -> int:
@@ -402,7 +418,19 @@ def main() -> None:
             for k in ("valu_pipe", "issue_cadence"):
                 roofline[k] = {"bound": k, "floor_us": round(ib[k]["floor_us"] * scale, 1),
                                "frac": round(ib[k]["floor_us"] * scale / (avg_ms * 1e3), 4)}
-            roofline["binding"] = (f"vector ALU: the launch's {ib['wave_instructions_per_launch']['valu'] * scale:.3g} VALU wave-instructions need "
+            if live and "valu_wave_instructions_per_launch" in live:
+                # the instruction count of THIS run's launches (third rocprofv3 --pmc child pass), priced with the
+                # profile's mean cycles per instruction of the kernel's static mix, at the clock of that pass
+                n_valu = live["valu_wave_instructions_per_launch"]
+                floor_us = n_valu * ib["mean_saturated_cycles_per_valu_instruction"] / 1024.0 / live["clock_GHz_under_pmc"] / 1e3
+                roofline["valu_pipe"] = {"bound": "valu_pipe", "floor_us": round(floor_us, 1), "frac": round(floor_us / live["launch_us_under_pmc"], 4),
+                                         "valu_wave_instructions_per_launch": n_valu,
+                                         "source": "SQ_INSTS_VALU of this run's launches (rocprofv3 --pmc child pass) x the kernel's mean "
+                                                   f"{ib['mean_saturated_cycles_per_valu_instruction']} cycles per instruction (static mix priced with the "
+                                                   "wall-clock-validated table) / 1024 SIMDs / the pass's clock, against the launch time of that pass"}
+                scale = None
+            n_show = live["valu_wave_instructions_per_launch"] if scale is None else ib["wave_instructions_per_launch"]["valu"] * scale
+            roofline["binding"] = (f"vector ALU: the launch's {n_show:.3g} VALU wave-instructions need "
                                    f"{roofline['valu_pipe']['frac']:.2f} of its time at their saturated rates ({ib.get('price_classes_cycles')} SIMD cycles per "
                                    "instruction by class, checked against wall-clock); the HBM stream needs "
                                    f"{roofline['frac']:.2f} (0.73 of the peak is what a 2:1 read:write stream reaches on this chip). The arithmetic is the "
