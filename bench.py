@@ -504,7 +504,7 @@ def main() -> None:
         q1 = time.perf_counter()
         plan1.close()
         one_pair = {"us_per_call": round(1e6 * (q1 - q0) / nrep, 1), "Mpix/s": round(nrep * H * W / (q1 - q0) / 1e6, 1),
-                    "note": "batch of 1: 15 dependent kernel launches, not the throughput figure"}
+                    "note": "batch of 1: 14 dependent kernel launches, not the throughput figure"}
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1) --------
     cpu = None
