@@ -383,6 +383,74 @@ def test_exit_decisions_next_to_the_threshold(oracle):
     assert redone >= 2, "the ladder never reached the uncertainty band: the construction is broken"
 
 
+def test_guard_band_follows_the_level_size(oracle):
+    """np.mean adds ceil(n / 8192) fp32 pieces one after the other, so its worst-case error grows with
+    the level: at 3840x2160 the band is (1013 + 32) * 2^-24 = 6.2e-5 relative, wider than the 5e-5 floor small
+    levels use.  A 4K level whose first mean lies 5.6e-5 above the threshold (bisected on the device's own exact
+    mean) must be flagged, and the redone pair must equal the oracle."""
+    import torch
+
+    import _oflk
+    from oflk_synth import synth_pair
+
+    H, W, L, K = 2160, 3840, 1, 2
+    prev, shifted = synth_pair(H, W, 0, dx=0.75, dy=-0.5)
+    delta = (shifted - prev).astype(np.float64)
+    dev = torch.device("cuda", 0)
+    d_prev = torch.from_numpy(prev[None]).to(dev)
+    u, v = torch.empty_like(d_prev), torch.empty_like(d_prev)
+    plan = _oflk.Plan(0, 1, H, W, L, 5, K)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(t):
+        c = (prev + t * delta).astype(np.float32)
+        d_curr = torch.from_numpy(c[None]).to(dev)
+        plan.pyramidal(d_prev.data_ptr(), d_curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+        log, runs = plan.read_log(st)
+        torch.cuda.synchronize()
+        return c, d_curr, float(max(log[0, 0, 0])), list(runs[0])
+
+    thr = float(np.float32(0.01))
+    target = thr * (1.0 + 5.6e-5)
+    lo, hi = 0.0, 1.0
+    assert run(lo)[2] < target < run(hi)[2]
+    # the mean moves in small jumps with t (a pixel crossing the solve's determinant threshold moves an 8.3 Mpx mean by
+    # ~1e-5 of the threshold): bisect towards the middle of the window, then walk t in fine steps around the crossing
+    got, seen = None, []
+    inside = lambda m: 5.15e-5 < m / thr - 1.0 < 6.1e-5
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        c, d_curr, m, runs = run(mid)
+        seen.append(m / thr - 1.0)
+        if inside(m):
+            got = (c, d_curr, m, runs)
+            break
+        if m < target:
+            lo = mid
+        else:
+            hi = mid
+    if got is None:
+        for i in range(-100, 101):
+            c, d_curr, m, runs = run(lo * (1.0 + i * 2e-7))
+            seen.append(m / thr - 1.0)
+            if inside(m):
+                got = (c, d_curr, m, runs)
+                break
+    assert got is not None, f"no input landed between the 5e-5 floor and the 4K band; closest {min(seen, key=lambda r: abs(r - 5.6e-5)):.3e}"
+    c, d_curr, m, runs = got
+    flags = plan.read_uncertain(st)
+    assert flags[0, 0] & 1, f"mean {m!r} is {m / thr - 1.0:.2e} above the threshold at 8.3 Mpx and was not flagged"
+    assert plan.resolve_uncertain(d_prev.data_ptr(), d_curr.data_ptr(), u.data_ptr(), v.data_ptr(), st) == 1
+    log, runs = plan.read_log(st)
+    torch.cuda.synchronize()
+    ou, ov, olog, oruns = oracle.lucas_kanade_pyramidal_ex(prev, c, L, 5, K)
+    assert list(runs[0]) == list(oruns)
+    _eq(u.cpu().numpy()[0], ou, "4K near-threshold u")
+    _eq(v.cpu().numpy()[0], ov, "4K near-threshold v")
+    np.testing.assert_array_equal(log[0, 0, :oruns[0]], olog[0, :oruns[0]])
+    plan.close()
+
+
 def test_resolve_uncertain_inside_a_batch(oracle):
     """Plan API: one near-threshold pair among ordinary ones; only that pair is redone, every pair ends up
     equal to the oracle; uint8 form included."""
