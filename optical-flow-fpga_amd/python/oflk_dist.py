@@ -33,11 +33,13 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 class Group:
     """Thin wrapper so single-process runs need no process group."""
 
-    def __init__(self, backend: Optional[str] = None, device=None):
+    def __init__(self, backend: Optional[str] = None, device=None, always: bool = False):
+        """always: create the process group even for one rank (a one-GPU box can then run the RCCL barrier / MAX / SUM
+        this module uses; tests/test_gpu_round3.py)."""
         self.rank, self.local_rank, self.world = env_rank()
         self.dist = None
         self.device = device
-        if self.world > 1:
+        if self.world > 1 or always:
             import torch.distributed as dist
 
             if not dist.is_initialized():

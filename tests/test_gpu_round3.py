@@ -244,3 +244,49 @@ def test_windows_beyond_45_are_refused_loudly(win):
     with pytest.raises(_oflk.OflkError) as e:
         K.lucas_kanade_single_scale_fp16(np.zeros((64, 64), np.float32), np.zeros((64, 64), np.float32), 13, 255.0)
     assert e.value.code == _oflk.OFLK_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------
+# RCCL on the box: the three small collectives of the multi-rank bench, on the device, one rank
+# ---------------------------------------------------------------------------------------------
+RCCL_WORKER = """
+import json, sys
+sys.path.insert(0, {product!r})
+import torch
+from oflk_dist import Group, job_layout, job_throughput, run_timed
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+g = Group("nccl", dev, always=True)
+assert g.dist is not None and g.dist.get_backend() == "nccl" and g.world == 1
+g.barrier()
+mx = g.max_over_ranks(1.25)
+sm = g.sum_over_ranks(41.0)
+objs = g.gather_objects({{"rank": g.rank}})
+lay = job_layout("4k64", g.rank, g.world, None, 24, 32)
+calls = []
+el = run_timed(g, lambda: calls.append(1), torch.cuda.synchronize, steps=3, warmup=1)
+job = job_throughput(g, lay, 3, el, {{"x": 2.0}})
+print("RESULT " + json.dumps({{"max": mx, "sum": sm, "objs": objs, "calls": len(calls), "pairs": job["pairs_per_step"], "x": job["sums"]["x"]}}))
+g.close()
+"""
+
+
+def test_rccl_collectives_of_the_bench_run_on_the_device(tmp_path):
+    """"RCCL itself has never been initialised by this code anywhere".  A one-GPU box cannot host two RCCL ranks,
+    but it can host one: the barrier, the MAX and SUM all-reduces on device tensors and the gather bench.py --gpus N uses
+    (oflk_dist.Group / run_timed / job_throughput), with backend nccl = RCCL, in a process of their own."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(product=str(root / "optical-flow-fpga_amd" / "python")))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    assert res == {"max": 1.25, "sum": 41.0, "objs": [{"rank": 0}], "calls": 4, "pairs": 64, "x": 2.0}
