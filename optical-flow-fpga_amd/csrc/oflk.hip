@@ -1447,6 +1447,12 @@ int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *cur
         }
         cv.notify_all();
         out_thread.join();
+        if (code != OFLK_OK || out_rc != OFLK_OK) {
+            // an abandoned batch may still have copies and kernels in flight on the ring buffers: the next call reuses them
+            (void)hipStreamSynchronize(c->s_in);
+            (void)hipStreamSynchronize(c->s_comp);
+            (void)hipStreamSynchronize(c->s_out);
+        }
         for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev_in[i]);
         if (code == OFLK_OK && out_rc != OFLK_OK) return fail(out_rc, "%s", out_msg.c_str());
         return code;
