@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Golden digests at BASELINE.json's full sizes, produced by IMPORTING THE REFERENCE (build container only; the
+reference needs minutes per frame pair at these sizes -- 1080p pyramidal: ~4 min, 4K: ~15 min on one core):
+  configs[1]  640x480    single-scale 5x5          (lucas_kanade_core.lucas_kanade_single_scale)
+  configs[2]  1920x1080  3 levels, 5x5, 3 iterations (lucas_kanade_pyramidal.lucas_kanade_pyramidal)
+  configs[3]  3840x2160  one pair of the 64-pair job, same parameters
+on the bench workload's synthetic frames (optical-flow-fpga_amd/python/oflk_synth.py, pair_index 0).
+Usage: python3 tests/golden/make_golden_fullsize.py [c1] [c2] [c3]   (default: c1 c2)
+Output: tests/golden/reference_fullsize.json (entries are merged into the existing file)."""
+import contextlib
+import hashlib
+import io
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, "/root/reference/python")
+import lucas_kanade_core as R_core  # noqa: E402  (reference)
+import lucas_kanade_pyramidal as R_pyr  # noqa: E402  (reference)
+
+R_pyr.visualize_pyramid_level = lambda *a, **k: None
+
+CASES = {
+    "c1": {"shape": [480, 640], "mode": "single_scale", "window_size": 5},
+    "c2": {"shape": [1080, 1920], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3},
+    "c3": {"shape": [2160, 3840], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3},
+}
+
+
+def digest(a):
+    a = np.ascontiguousarray(a, np.float32) + np.float32(0.0)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def synth(h, w):
+    # the product's generator, loaded by path so that the reference's modules (same names as the shims) stay the ones imported above
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("oflk_synth", HERE.parents[1] / "optical-flow-fpga_amd" / "python" / "oflk_synth.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.synth_pair(h, w, pair_index=0)
+
+
+def main():
+    want = sys.argv[1:] or ["c1", "c2"]
+    path = HERE / "reference_fullsize.json"
+    out = json.loads(path.read_text()) if path.exists() else {}
+    for key in want:
+        c = dict(CASES[key])
+        h, w = c["shape"]
+        p, q = synth(h, w)
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            if c["mode"] == "single_scale":
+                u, v = R_core.lucas_kanade_single_scale(p, q, c["window_size"])
+            else:
+                u, v = R_pyr.lucas_kanade_pyramidal(p, q, c["levels"], c["window_size"], c["iterations"])
+        c.update(pair_index=0, u_sha256=digest(u), v_sha256=digest(v), mean_abs_u=float(np.abs(u).mean(dtype=np.float64)),
+                 mean_abs_v=float(np.abs(v).mean(dtype=np.float64)), reference_seconds=round(time.time() - t0, 1))
+        out[key] = c
+        print(key, c, flush=True)
+        path.write_text(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

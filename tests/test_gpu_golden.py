@@ -164,3 +164,24 @@ def test_uint8_ingestion_equals_float_path(suite):
     u8 = K.lucas_kanade_single_scale(a, b, 5)
     uf = K.lucas_kanade_single_scale(a.astype(np.float32), b.astype(np.float32), 5)
     assert np.array_equal(u8[0], uf[0]) and np.array_equal(u8[1], uf[1])
+
+
+@pytest.mark.parametrize("key", ["c1", "c2", "c3"])
+def test_hip_equals_the_reference_at_baseline_sizes(golden_dir, key):
+    """BASELINE.json configs[1], [2] and one pair of [3] on the bench workload's frames: HIP digests == the digests of the
+    reference's own output (tests/golden/reference_fullsize.json); float32 and uint8 frames."""
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+    from oflk_synth import synth_pair
+
+    cases = json.loads((golden_dir / "reference_fullsize.json").read_text())
+    if key not in cases:
+        pytest.skip(f"{key} not in reference_fullsize.json")
+    c = cases[key]
+    p, q = synth_pair(*c["shape"], pair_index=c["pair_index"])
+    for frames in ((p, q), (p.astype(np.uint8), q.astype(np.uint8))):
+        if c["mode"] == "single_scale":
+            u, v = K.lucas_kanade_single_scale(frames[0], frames[1], c["window_size"])
+        else:
+            u, v = P.lucas_kanade_pyramidal(frames[0], frames[1], c["levels"], c["window_size"], c["iterations"])
+        assert digest(u) == c["u_sha256"] and digest(v) == c["v_sha256"]

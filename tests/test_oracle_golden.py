@@ -219,3 +219,28 @@ def test_windows_outside_3_to_11_match_the_reference(oracle, golden_dir):
         for win, d in e["pyramidal"].items():
             u, v = oracle.lucas_kanade_pyramidal(p, c, d["levels"], int(win), d["iterations"])
             assert digest(u) == d["u_sha256"] and digest(v) == d["v_sha256"], (name, win)
+
+
+def _fullsize_cases(golden_dir):
+    import json
+
+    return json.loads((golden_dir / "reference_fullsize.json").read_text())
+
+
+@pytest.mark.parametrize("key", ["c1", "c2", "c3"])
+def test_oracle_equals_the_reference_at_baseline_sizes(oracle, golden_dir, key):
+    """BASELINE.json configs[1] (640x480 single-scale), configs[2] (1920x1080, 3 levels) and one pair of configs[3]
+    (3840x2160) on the bench workload's synthetic frames: the oracle's flow equals the reference's own
+    (tests/golden/reference_fullsize.json, made by importing the reference: minutes per pair there, seconds here)."""
+    from oflk_synth import synth_pair
+
+    cases = _fullsize_cases(golden_dir)
+    if key not in cases:
+        pytest.skip(f"{key} not in reference_fullsize.json")
+    c = cases[key]
+    p, q = synth_pair(*c["shape"], pair_index=c["pair_index"])
+    if c["mode"] == "single_scale":
+        u, v = oracle.lucas_kanade_single_scale(p, q, c["window_size"])
+    else:
+        u, v = oracle.lucas_kanade_pyramidal(p, q, c["levels"], c["window_size"], c["iterations"])
+    assert digest(u) == c["u_sha256"] and digest(v) == c["v_sha256"]
