@@ -539,6 +539,25 @@ def main() -> None:
         if local_rank != 0:
             _oflk.check(_oflk.lib().oflk_set_device(local_rank))
         parity = epe_vs_reference()
+        # pair 0 of THIS workload against the reference's own output on it (tests/golden/reference_fullsize.json, made by
+        # importing the reference: 3 minutes for the 1080p pair, 15 for the 4K one); u[0], v[0] as the batch plan (or the one-pair
+        # plan after it: same values) left them
+        try:
+            full = json.loads((ROOT / "tests" / "golden" / "reference_fullsize.json").read_text())
+        except Exception:
+            full = {}
+        for key, c in full.items():
+            if (parity is not None and lay.pair_begin == 0 and c.get("mode") == "pyramidal" and c["shape"] == [H, W] and
+                    [c["levels"], c["window_size"], c["iterations"]] == [L, args.window, K] and c["pair_index"] == 0):
+                import hashlib
+
+                def dg(t):
+                    return hashlib.sha256((np.ascontiguousarray(t.cpu().numpy(), np.float32) + np.float32(0.0)).tobytes()).hexdigest()
+
+                eq = int(dg(u[0]) == c["u_sha256"]) + int(dg(v[0]) == c["v_sha256"])
+                parity["workload_pair0"] = {"flow_fields": 2, "digests_equal": eq, "mean_epe": 0.0 if eq == 2 else None,
+                                            "source": f"tests/golden/reference_fullsize.json[{key}]: the reference's own flow of pair 0 "
+                                                      f"of this workload ({c['reference_seconds']} s on one core there)"}
     if rank == 0:
         out = {
             "metric": "Mpix/s dense flow (1080p pyramidal)" if (H, W) == (1080, 1920) else "Mpix/s dense flow",
