@@ -533,6 +533,15 @@ def main() -> None:
             c1 = time.perf_counter()
             cpu["all_cores"] = {"value": round(n * H * W / (c1 - c0) / 1e6, 4), "cores": nt}
             O.set_threads(1)
+        # the Python reference itself cannot travel to this box; its time on pair 0 of this workload was recorded where
+        # the golden digests were made (tests/golden/make_golden_fullsize.py, the build container, one core)
+        try:
+            for c in json.loads((ROOT / "tests" / "golden" / "reference_fullsize.json").read_text()).values():
+                if c.get("mode") == "pyramidal" and c["shape"] == [H, W] and [c["levels"], c["window_size"], c["iterations"]] == [L, args.window, K]:
+                    cpu["python_reference_in_build_container"] = {"value": round(H * W / c["reference_seconds"] / 1e6, 5), "unit": "Mpix/s",
+                                                                  "cores": 1, "seconds_per_pair": c["reference_seconds"]}
+        except Exception:
+            pass
 
     parity = None
     if rank == 0 and not args.no_parity:

@@ -4,8 +4,9 @@ reference needs minutes per frame pair at these sizes -- 1080p pyramidal: ~4 min
   configs[1]  640x480    single-scale 5x5          (lucas_kanade_core.lucas_kanade_single_scale)
   configs[2]  1920x1080  3 levels, 5x5, 3 iterations (lucas_kanade_pyramidal.lucas_kanade_pyramidal)
   configs[3]  3840x2160  one pair of the 64-pair job, same parameters
+  configs[4]  7680x4320  single-scale 7x7 in the reference's own fp32 (what the opt-in fp16 mode is measured against)
 on the bench workload's synthetic frames (optical-flow-fpga_amd/python/oflk_synth.py, pair_index 0).
-Usage: python3 tests/golden/make_golden_fullsize.py [c1] [c2] [c3]   (default: c1 c2)
+Usage: python3 tests/golden/make_golden_fullsize.py [c1] [c2] [c3] [c4]   (default: c1 c2)
 Output: tests/golden/reference_fullsize.json (entries are merged into the existing file)."""
 import contextlib
 import hashlib
@@ -28,6 +29,7 @@ CASES = {
     "c1": {"shape": [480, 640], "mode": "single_scale", "window_size": 5},
     "c2": {"shape": [1080, 1920], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3},
     "c3": {"shape": [2160, 3840], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3},
+    "c4": {"shape": [4320, 7680], "mode": "single_scale", "window_size": 7},
 }
 
 
@@ -48,7 +50,9 @@ def synth(h, w):
 
 def main():
     want = sys.argv[1:] or ["c1", "c2"]
-    path = HERE / "reference_fullsize.json"
+    import os
+
+    path = Path(os.environ.get("GOLD_OUT", HERE / "reference_fullsize.json"))   # (a second process writes elsewhere; merge by hand)
     out = json.loads(path.read_text()) if path.exists() else {}
     for key in want:
         c = dict(CASES[key])

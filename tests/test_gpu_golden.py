@@ -166,9 +166,9 @@ def test_uint8_ingestion_equals_float_path(suite):
     assert np.array_equal(u8[0], uf[0]) and np.array_equal(u8[1], uf[1])
 
 
-@pytest.mark.parametrize("key", ["c1", "c2", "c3"])
+@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4"])
 def test_hip_equals_the_reference_at_baseline_sizes(golden_dir, key):
-    """BASELINE.json configs[1], [2] and one pair of [3] on the bench workload's frames: HIP digests == the digests of the
+    """BASELINE.json configs[1], [2], one pair of [3] and [4] (its exact fp32 form) on the bench workload's frames: HIP digests == the digests of the
     reference's own output (tests/golden/reference_fullsize.json); float32 and uint8 frames."""
     import lucas_kanade_core as K
     import lucas_kanade_pyramidal as P
