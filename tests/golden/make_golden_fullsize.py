@@ -30,6 +30,14 @@ CASES = {
     "c2": {"shape": [1080, 1920], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3},
     "c3": {"shape": [2160, 3840], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3},
     "c4": {"shape": [4320, 7680], "mode": "single_scale", "window_size": 7},
+    # other parameters and odd shapes at a size the reference finishes in a minute (pair_index = another seed)
+    "m1": {"shape": [480, 640], "mode": "pyramidal", "levels": 4, "window_size": 5, "iterations": 5, "pair_index": 1},
+    "m2": {"shape": [480, 640], "mode": "pyramidal", "levels": 3, "window_size": 7, "iterations": 2, "pair_index": 2},
+    "m3": {"shape": [480, 640], "mode": "pyramidal", "levels": 2, "window_size": 9, "iterations": 3, "pair_index": 3},
+    "m4": {"shape": [480, 640], "mode": "pyramidal", "levels": 3, "window_size": 11, "iterations": 1, "pair_index": 4},
+    "m5": {"shape": [481, 643], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3, "pair_index": 5},
+    "m6": {"shape": [360, 1001], "mode": "pyramidal", "levels": 3, "window_size": 3, "iterations": 3, "pair_index": 6},
+    "m7": {"shape": [555, 333], "mode": "single_scale", "window_size": 9, "pair_index": 7},
 }
 
 
@@ -38,14 +46,14 @@ def digest(a):
     return hashlib.sha256(a.tobytes()).hexdigest()
 
 
-def synth(h, w):
+def synth(h, w, pair_index=0):
     # the product's generator, loaded by path so that the reference's modules (same names as the shims) stay the ones imported above
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("oflk_synth", HERE.parents[1] / "optical-flow-fpga_amd" / "python" / "oflk_synth.py")
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    return m.synth_pair(h, w, pair_index=0)
+    return m.synth_pair(h, w, pair_index=pair_index)
 
 
 def main():
@@ -57,14 +65,15 @@ def main():
     for key in want:
         c = dict(CASES[key])
         h, w = c["shape"]
-        p, q = synth(h, w)
+        c.setdefault("pair_index", 0)
+        p, q = synth(h, w, c["pair_index"])
         t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             if c["mode"] == "single_scale":
                 u, v = R_core.lucas_kanade_single_scale(p, q, c["window_size"])
             else:
                 u, v = R_pyr.lucas_kanade_pyramidal(p, q, c["levels"], c["window_size"], c["iterations"])
-        c.update(pair_index=0, u_sha256=digest(u), v_sha256=digest(v), mean_abs_u=float(np.abs(u).mean(dtype=np.float64)),
+        c.update(u_sha256=digest(u), v_sha256=digest(v), mean_abs_u=float(np.abs(u).mean(dtype=np.float64)),
                  mean_abs_v=float(np.abs(v).mean(dtype=np.float64)), reference_seconds=round(time.time() - t0, 1))
         out[key] = c
         print(key, c, flush=True)

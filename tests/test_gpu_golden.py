@@ -166,7 +166,7 @@ def test_uint8_ingestion_equals_float_path(suite):
     assert np.array_equal(u8[0], uf[0]) and np.array_equal(u8[1], uf[1])
 
 
-@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4"])
+@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4", "m1", "m2", "m3", "m4", "m5", "m6", "m7"])
 def test_hip_equals_the_reference_at_baseline_sizes(golden_dir, key):
     """BASELINE.json configs[1], [2], one pair of [3] and [4] (its exact fp32 form) on the bench workload's frames: HIP digests == the digests of the
     reference's own output (tests/golden/reference_fullsize.json); float32 and uint8 frames."""

@@ -227,7 +227,7 @@ def _fullsize_cases(golden_dir):
     return json.loads((golden_dir / "reference_fullsize.json").read_text())
 
 
-@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4"])
+@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4", "m1", "m2", "m3", "m4", "m5", "m6", "m7"])
 def test_oracle_equals_the_reference_at_baseline_sizes(oracle, golden_dir, key):
     """BASELINE.json configs[1] (640x480 single-scale), configs[2] (1920x1080, 3 levels), one pair of configs[3]
     (3840x2160) and configs[4] in the reference's own fp32 (7680x4320, 7x7 single-scale) on the bench workload's synthetic frames: the oracle's flow equals the reference's own
