@@ -32,3 +32,13 @@ def synth_pair(H: int, W: int, pair_index: int = 0, dx: float = 3.0, dy: float =
     f1 = shift(f0.astype(np.float64), (dy, dx), order=1, mode="constant", cval=128.0)
     f1 = np.clip(f1, 0, 255).astype(np.uint8)
     return f0.astype(np.float32), f1.astype(np.float32)
+
+
+def synth_flow(H: int, W: int, seed: int = 0, amplitude: float = 3.0) -> Tuple[np.ndarray, np.ndarray]:
+    """A smooth float32 flow field (u, v) with sub-pixel noise, for tests of warp_image / upsample_flow at any size:
+    generic fractions, a few samples that leave the image at the borders."""
+    rng = np.random.default_rng(BASE_SEED + 7919 * (int(seed) + 1))
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    u = amplitude * np.sin(x / 50.0) * np.cos(y / 70.0) + rng.normal(0.0, 0.3, (H, W))
+    v = amplitude * 0.5 * np.cos(x / 35.0 + 0.4) * np.sin(y / 45.0) + rng.normal(0.0, 0.3, (H, W))
+    return u.astype(np.float32), v.astype(np.float32)

@@ -244,3 +244,26 @@ def test_oracle_equals_the_reference_at_baseline_sizes(oracle, golden_dir, key):
     else:
         u, v = oracle.lucas_kanade_pyramidal(p, q, c["levels"], c["window_size"], c["iterations"])
     assert digest(u) == c["u_sha256"] and digest(v) == c["v_sha256"]
+
+
+@pytest.mark.parametrize("key", ["1080p", "4k", "odd"])
+def test_oracle_stage_functions_equal_the_reference_at_full_size(oracle, golden_dir, key):
+    """compute_gradients, build_gaussian_pyramid, warp_image, upsample_flow at 1920x1080, 3840x2160 and 1081x1923:
+    digests of the reference's own output (tests/golden/reference_stages_fullsize.json, make_golden_stages_fullsize.py)."""
+    import json
+
+    from oflk_synth import synth_flow, synth_pair
+
+    r = json.loads((golden_dir / "reference_stages_fullsize.json").read_text())[key]
+    h, w = r["shape"]
+    p, c = synth_pair(h, w, pair_index=0)
+    ix, iy, it = oracle.compute_gradients(p, c)
+    assert [digest(ix), digest(iy), digest(it)] == r["gradients"]
+    pyr = oracle.build_gaussian_pyramid(c, 3)
+    assert [list(a.shape) for a in pyr] == r["pyramid_shapes"] and [digest(a) for a in pyr] == r["pyramid"]
+    fu, fv = synth_flow(h, w, seed=1)
+    assert digest(oracle.warp_image(c, fu, fv)) == r["warp"]
+    hc, wc = r["upsample_from"]
+    cu, cv = synth_flow(hc, wc, seed=2)
+    uu, uv = oracle.upsample_flow(cu, cv, (h, w))
+    assert [digest(uu), digest(uv)] == r["upsample"]
