@@ -42,3 +42,16 @@ def synth_flow(H: int, W: int, seed: int = 0, amplitude: float = 3.0) -> Tuple[n
     u = amplitude * np.sin(x / 50.0) * np.cos(y / 70.0) + rng.normal(0.0, 0.3, (H, W))
     v = amplitude * 0.5 * np.cos(x / 35.0 + 0.4) * np.sin(y / 45.0) + rng.normal(0.0, 0.3, (H, W))
     return u.astype(np.float32), v.astype(np.float32)
+
+
+def synth_pair_smooth(H: int, W: int, pair_index: int = 0, dx: float = 0.3, dy: float = 0.1
+                      ) -> Tuple[np.ndarray, np.ndarray]:
+    """Noise-free float32 frames (not 8-bit): the texture of synth_pair blurred, curr = a cubic sub-pixel shift of it.
+    Small motions converge within an iteration or two, so pyramid levels leave their loop early
+    (lucas_kanade_pyramidal.py:221-223) at different iteration counts."""
+    from scipy.ndimage import gaussian_filter, shift
+
+    p, _ = synth_pair(H, W, pair_index)
+    p = gaussian_filter(p.astype(np.float64), 2.0)
+    c = shift(p, (dy, dx), order=3, mode="nearest")
+    return p.astype(np.float32), c.astype(np.float32)

@@ -38,6 +38,10 @@ CASES = {
     "m5": {"shape": [481, 643], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 3, "pair_index": 5},
     "m6": {"shape": [360, 1001], "mode": "pyramidal", "levels": 3, "window_size": 3, "iterations": 3, "pair_index": 6},
     "m7": {"shape": [555, 333], "mode": "single_scale", "window_size": 9, "pair_index": 7},
+    # small motions: levels leave their iteration loop early (lucas_kanade_pyramidal.py:221-223); identical frames
+    "e1": {"shape": [480, 640], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 4, "pair_index": 8, "dx": 0.0, "dy": 0.0},
+    "e2": {"shape": [480, 640], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 4, "pair_index": 9, "dx": 0.04, "dy": -0.02, "smooth": True},
+    "e3": {"shape": [480, 640], "mode": "pyramidal", "levels": 3, "window_size": 5, "iterations": 4, "pair_index": 10, "dx": 0.3, "dy": 0.1, "smooth": True},
 }
 
 
@@ -46,14 +50,14 @@ def digest(a):
     return hashlib.sha256(a.tobytes()).hexdigest()
 
 
-def synth(h, w, pair_index=0):
+def synth(h, w, pair_index=0, dx=3.0, dy=-1.5, smooth=False):
     # the product's generator, loaded by path so that the reference's modules (same names as the shims) stay the ones imported above
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("oflk_synth", HERE.parents[1] / "optical-flow-fpga_amd" / "python" / "oflk_synth.py")
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    return m.synth_pair(h, w, pair_index=pair_index)
+    return (m.synth_pair_smooth if smooth else m.synth_pair)(h, w, pair_index, dx, dy)
 
 
 def main():
@@ -66,15 +70,25 @@ def main():
         c = dict(CASES[key])
         h, w = c["shape"]
         c.setdefault("pair_index", 0)
-        p, q = synth(h, w, c["pair_index"])
+        p, q = synth(h, w, c["pair_index"], c.get("dx", 3.0), c.get("dy", -1.5), c.get("smooth", False))
         t0 = time.time()
-        with contextlib.redirect_stdout(io.StringIO()):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
             if c["mode"] == "single_scale":
                 u, v = R_core.lucas_kanade_single_scale(p, q, c["window_size"])
             else:
                 u, v = R_pyr.lucas_kanade_pyramidal(p, q, c["levels"], c["window_size"], c["iterations"])
         c.update(u_sha256=digest(u), v_sha256=digest(v), mean_abs_u=float(np.abs(u).mean(dtype=np.float64)),
                  mean_abs_v=float(np.abs(v).mean(dtype=np.float64)), reference_seconds=round(time.time() - t0, 1))
+        if c["mode"] == "pyramidal":
+            # iterations the reference ran per level, counted from the residual lines it prints (coarse -> fine)
+            runs = []
+            for line in buf.getvalue().splitlines():
+                if line.startswith("Processing pyramid level"):
+                    runs.append(0)
+                elif line.startswith("  Iteration ") and runs:
+                    runs[-1] += 1
+            c["iters_run"] = runs
         out[key] = c
         print(key, c, flush=True)
         path.write_text(json.dumps(out, indent=1))

@@ -166,24 +166,30 @@ def test_uint8_ingestion_equals_float_path(suite):
     assert np.array_equal(u8[0], uf[0]) and np.array_equal(u8[1], uf[1])
 
 
-@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4", "m1", "m2", "m3", "m4", "m5", "m6", "m7"])
+@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4", "m1", "m2", "m3", "m4", "m5", "m6", "m7", "e1", "e2", "e3"])
 def test_hip_equals_the_reference_at_baseline_sizes(golden_dir, key):
-    """BASELINE.json configs[1], [2], one pair of [3] and [4] (its exact fp32 form) on the bench workload's frames: HIP digests == the digests of the
-    reference's own output (tests/golden/reference_fullsize.json); float32 and uint8 frames."""
+    """BASELINE.json configs[1], [2], one pair of [3] and [4] (its exact fp32 form) on the bench workload's frames, mid-size
+    cases with other parameters and odd shapes (m*), small motions whose levels exit early (e*): HIP digests and iteration
+    counts == those of the reference's own run (tests/golden/reference_fullsize.json); float32 and, where the frames are
+    8-bit, uint8 arrays."""
     import lucas_kanade_core as K
     import lucas_kanade_pyramidal as P
-    from oflk_synth import synth_pair
+    from oflk_synth import synth_pair, synth_pair_smooth
 
     cases = json.loads((golden_dir / "reference_fullsize.json").read_text())
     if key not in cases:
         pytest.skip(f"{key} not in reference_fullsize.json")
     c = cases[key]
-    p, q = synth_pair(*c["shape"], pair_index=c["pair_index"])
-    for frames in ((p, q), (p.astype(np.uint8), q.astype(np.uint8))):
+    gen = synth_pair_smooth if c.get("smooth") else synth_pair
+    p, q = gen(c["shape"][0], c["shape"][1], c["pair_index"], c.get("dx", 3.0), c.get("dy", -1.5))
+    forms = [(p, q)] + ([] if c.get("smooth") else [(p.astype(np.uint8), q.astype(np.uint8))])
+    for frames in forms:
         if c["mode"] == "single_scale":
             u, v = K.lucas_kanade_single_scale(frames[0], frames[1], c["window_size"])
         else:
-            u, v = P.lucas_kanade_pyramidal(frames[0], frames[1], c["levels"], c["window_size"], c["iterations"])
+            u, v, _, runs = P.lucas_kanade_pyramidal_with_log(frames[0], frames[1], c["levels"], c["window_size"], c["iterations"])
+            if "iters_run" in c:
+                assert list(runs[:c["levels"]]) == c["iters_run"]
         assert digest(u) == c["u_sha256"] and digest(v) == c["v_sha256"]
 
 

@@ -221,28 +221,40 @@ def test_windows_outside_3_to_11_match_the_reference(oracle, golden_dir):
             assert digest(u) == d["u_sha256"] and digest(v) == d["v_sha256"], (name, win)
 
 
+FULLSIZE_KEYS = ["c1", "c2", "c3", "c4", "m1", "m2", "m3", "m4", "m5", "m6", "m7", "e1", "e2", "e3"]
+
+
+def _fullsize_frames(c):
+    from oflk_synth import synth_pair, synth_pair_smooth
+
+    gen = synth_pair_smooth if c.get("smooth") else synth_pair
+    return gen(c["shape"][0], c["shape"][1], c["pair_index"], c.get("dx", 3.0), c.get("dy", -1.5))
+
+
 def _fullsize_cases(golden_dir):
     import json
 
     return json.loads((golden_dir / "reference_fullsize.json").read_text())
 
 
-@pytest.mark.parametrize("key", ["c1", "c2", "c3", "c4", "m1", "m2", "m3", "m4", "m5", "m6", "m7"])
+@pytest.mark.parametrize("key", FULLSIZE_KEYS)
 def test_oracle_equals_the_reference_at_baseline_sizes(oracle, golden_dir, key):
     """BASELINE.json configs[1] (640x480 single-scale), configs[2] (1920x1080, 3 levels), one pair of configs[3]
-    (3840x2160) and configs[4] in the reference's own fp32 (7680x4320, 7x7 single-scale) on the bench workload's synthetic frames: the oracle's flow equals the reference's own
-    (tests/golden/reference_fullsize.json, made by importing the reference: minutes per pair there, seconds here)."""
-    from oflk_synth import synth_pair
-
+    (3840x2160) and configs[4] in the reference's own fp32 (7680x4320, 7x7 single-scale) on the bench workload's synthetic
+    frames, mid-size cases with other parameters (m*) and small motions whose levels exit early (e*): the oracle's flow and
+    iteration counts equal the reference's own (tests/golden/reference_fullsize.json, made by importing the reference:
+    minutes per pair there, seconds here)."""
     cases = _fullsize_cases(golden_dir)
     if key not in cases:
         pytest.skip(f"{key} not in reference_fullsize.json")
     c = cases[key]
-    p, q = synth_pair(*c["shape"], pair_index=c["pair_index"])
+    p, q = _fullsize_frames(c)
     if c["mode"] == "single_scale":
         u, v = oracle.lucas_kanade_single_scale(p, q, c["window_size"])
     else:
-        u, v = oracle.lucas_kanade_pyramidal(p, q, c["levels"], c["window_size"], c["iterations"])
+        u, v, _, runs = oracle.lucas_kanade_pyramidal_ex(p, q, c["levels"], c["window_size"], c["iterations"])
+        if "iters_run" in c:
+            assert list(runs) == c["iters_run"]
     assert digest(u) == c["u_sha256"] and digest(v) == c["v_sha256"]
 
 
