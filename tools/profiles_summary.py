@@ -29,6 +29,7 @@ def main():
 | `{tag}_contracted_epe.json`, `{tag}_host_latency.txt` | `tests/test_gpu_round3.py`, `tools/host_latency.py` | opt-in contracted arithmetic: flow values that differ from the exact result, pyramid kernel time; host-to-host timings (single pairs, and 32 pairs in one chunked call) |
 | `{tag}_stamps_timeline.{{txt,json}}`, `{tag}_block_times.json` | `tools/stamps.py`, `tools/block_times.py` (diagnostic builds) | where a wave spends a tile's time (13 sections); block lifetimes: slot occupancy {bt['slot_occupancy_mean']}, {bt['per_block_us']['per_tile']} µs per tile, prologue {bt['per_block_us']['prologue']} µs, refill gap {bt['slot_refill_gap_us']['mean']} µs |
 | `{tag}_one_pair_timeline.txt` | `rocprofv3 --kernel-trace -- python3 tools/kbench.py --pairs 1` | the 14 dependent launches of ONE 1080p pair per call, and the call with 64 x 8 / 16 / 24 tiles |
+| `{tag}_grid_barrier.txt` | `tools/ubench/grid_barrier` | a dependent kernel launch (2.3 - 2.9 µs) against a device-scope grid barrier inside one launch (8 - 107 µs for 96 - 1 024 blocks) |
 | `{tag}_configs.json` | `tools/measure_configs.py` | every BASELINE config that fits one GPU + the f3 integer mode (table below) |
 | `{tag}_bench_4k64_1gpu.json` | `python bench.py --config 4k64` | BASELINE configs[3] (64 pairs of 4K, one job) on one GPU |
 | `{tag}_fp16_epe.json`, `{tag}_pmc_fp16.txt`, `{tag}_rowwalk.txt`, `{tag}_hbm_probe.txt` | `tests/test_gpu_fp16.py`, `tools/pmc_fp16.sh`, `tools/ubench/rowwalk`, `tools/hbm_probe.py` | fp16 mode: EPE against the exact path per pattern; counters of the streaming kernel; what the HBM gives the same read/write mix by access pattern; library elementwise kernels as the practical ceiling |
