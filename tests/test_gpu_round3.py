@@ -290,3 +290,53 @@ def test_rccl_collectives_of_the_bench_run_on_the_device(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
     assert res == {"max": 1.25, "sum": 41.0, "objs": [{"rank": 0}], "calls": 4, "pairs": 64, "x": 2.0}
+
+
+# ---------------------------------------------------------------------------------------------
+# arrays beyond 4 GiB: every pair of a very large batch is addressed (64-bit pair offsets, 32-bit offsets inside a plane)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("u8", [False, True])
+def test_batches_beyond_4_gib_address_every_pair(u8):
+    """640 pairs of 1920x1080 in one plan call: 5.3 GB per float32 array, 10.6 GB per interleaved flow slot.  The batch is four
+    distinct pairs repeated, so pair b must equal pair b % 4 -- of the same call and of a four-pair call."""
+    import torch
+
+    import _oflk
+    from oflk_synth import synth_pair
+
+    B, H, W, L, K = 640, 1080, 1920, 3, 3
+    dev = torch.device("cuda", 0)
+    dt = torch.uint8 if u8 else torch.float32
+    host = [synth_pair(H, W, pair_index=i) for i in range(4)]
+    small_p = torch.stack([torch.from_numpy(p) for p, _ in host]).to(dev).to(dt)
+    small_c = torch.stack([torch.from_numpy(c) for _, c in host]).to(dev).to(dt)
+    prev = small_p.repeat(B // 4, 1, 1).contiguous()
+    curr = small_c.repeat(B // 4, 1, 1).contiguous()
+    assert prev.numel() * prev.element_size() > (1 << 32) or u8
+    u = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    v = torch.empty_like(u)
+    assert u.numel() * 4 > (1 << 32)
+    st = torch.cuda.current_stream().cuda_stream
+    big = _oflk.Plan(0, B, H, W, L, 5, K)
+    call = big.pyramidal_u8 if u8 else big.pyramidal
+    call(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+    _, runs = big.read_log(st)
+    torch.cuda.synchronize()
+    su, sv = torch.empty((4, H, W), dtype=torch.float32, device=dev), torch.empty((4, H, W), dtype=torch.float32, device=dev)
+    small = _oflk.Plan(0, 4, H, W, L, 5, K)
+    (small.pyramidal_u8 if u8 else small.pyramidal)(small_p.data_ptr(), small_c.data_ptr(), su.data_ptr(), sv.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(u.view(B // 4, 4, H, W), su.unsqueeze(0).expand(B // 4, 4, H, W))
+    assert torch.equal(v.view(B // 4, 4, H, W), sv.unsqueeze(0).expand(B // 4, 4, H, W))
+    assert (np.asarray(runs) == 3).all()
+    # single-scale through the same plan (planar outputs only)
+    big.single_scale_u8(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), st) if u8 else \
+        big.single_scale(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+    (small.single_scale_u8 if u8 else small.single_scale)(small_p.data_ptr(), small_c.data_ptr(), su.data_ptr(), sv.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(u.view(B // 4, 4, H, W), su.unsqueeze(0).expand(B // 4, 4, H, W))
+    assert torch.equal(v.view(B // 4, 4, H, W), sv.unsqueeze(0).expand(B // 4, 4, H, W))
+    big.close()
+    small.close()
+    del prev, curr, u, v
+    torch.cuda.empty_cache()
