@@ -5,8 +5,12 @@ reference needs minutes per frame pair at these sizes -- 1080p pyramidal: ~4 min
   configs[2]  1920x1080  3 levels, 5x5, 3 iterations (lucas_kanade_pyramidal.lucas_kanade_pyramidal)
   configs[3]  3840x2160  one pair of the 64-pair job, same parameters
   configs[4]  7680x4320  single-scale 7x7 in the reference's own fp32 (what the opt-in fp16 mode is measured against)
-on the bench workload's synthetic frames (optical-flow-fpga_amd/python/oflk_synth.py, pair_index 0).
-Usage: python3 tests/golden/make_golden_fullsize.py [c1] [c2] [c3] [c4]   (default: c1 c2)
+on the bench workload's synthetic frames (optical-flow-fpga_amd/python/oflk_synth.py, pair_index 0); plus
+  m1 .. m7   mid-size cases with other levels / iterations / windows and odd shapes (5 - 70 s each)
+  e1 .. e3   small motions (identical frames; smooth frames shifted by a fraction of a pixel) whose levels leave the
+             iteration loop early: the iteration counts are read from the lines the reference prints
+Usage: python3 tests/golden/make_golden_fullsize.py [c1 .. c4] [m1 .. m7] [e1 .. e3]   (default: c1 c2)
+       GOLD_OUT=/tmp/x.json ... writes to another file (a second process running beside the first; merge by hand)
 Output: tests/golden/reference_fullsize.json (entries are merged into the existing file)."""
 import contextlib
 import hashlib
