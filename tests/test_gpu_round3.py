@@ -340,3 +340,98 @@ def test_batches_beyond_4_gib_address_every_pair(u8):
     small.close()
     del prev, curr, u, v
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------
+# host entry points from several threads at once (one context and mutex per device; ctypes releases the GIL)
+# ---------------------------------------------------------------------------------------------
+def test_concurrent_host_calls_from_several_threads():
+    """Four threads call the drop-in functions at the same time on different shapes / modes (float32, uint8, single-scale,
+    pyramidal, a chunked batch through the C ABI): every result equals the one the same call gives on its own, and an
+    error raised in one thread (a window the library refuses) does not leak into the others' error state."""
+    import threading
+
+    import _oflk
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+    from oflk_synth import synth_pair
+
+    jobs = []
+    for i, (shape, kind) in enumerate([((120, 160), "pyr"), ((240, 320), "single"), ((97, 131), "pyr_u8"), ((200, 300), "single7")]):
+        p, c = synth_pair(*shape, pair_index=i)
+        if kind == "pyr":
+            fn = lambda p=p, c=c: P.lucas_kanade_pyramidal(p, c, 3, 5, 3)
+        elif kind == "single":
+            fn = lambda p=p, c=c: K.lucas_kanade_single_scale(p, c, 5)
+        elif kind == "pyr_u8":
+            fn = lambda p=p, c=c: P.lucas_kanade_pyramidal(p.astype(np.uint8), c.astype(np.uint8), 2, 5, 2)
+        else:
+            fn = lambda p=p, c=c: K.lucas_kanade_single_scale(p, c, 7)
+        jobs.append(fn)
+    want = [fn() for fn in jobs]
+    errors, mismatches = [], []
+
+    def worker(k):
+        try:
+            for rep in range(25):
+                u, v = jobs[k]()
+                if not (np.array_equal(u, want[k][0]) and np.array_equal(v, want[k][1])):
+                    mismatches.append((k, rep))
+                if k == 3 and rep % 5 == 0:   # a refused call in between: the message belongs to this thread alone
+                    try:
+                        K.lucas_kanade_single_scale(want[k][0], want[k][1], 101)
+                        errors.append("window 101 was accepted")
+                    except _oflk.OflkError as e:
+                        if "101" not in str(e):
+                            errors.append(f"foreign error text: {e}")
+        except Exception as e:   # noqa: BLE001
+            errors.append(f"thread {k}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a host call hangs under concurrency"
+    assert not errors, errors[:3]
+    assert not mismatches, mismatches[:5]
+
+
+def test_two_plans_on_two_streams_from_two_threads(oracle):
+    """Plan API: a plan is single-stream, but two plans are independent -- two threads enqueue 40 passes each on their own
+    plan and stream at the same time; both end with the oracle's flow."""
+    import threading
+
+    import torch
+
+    import _oflk
+    from oflk_synth import synth_pair
+
+    dev = torch.device("cuda", 0)
+    cases = []
+    for i, (H, W, L, K) in enumerate([(240, 320, 3, 3), (300, 200, 2, 2)]):
+        p, c = synth_pair(H, W, pair_index=20 + i)
+        d = {"p": torch.from_numpy(p[None]).to(dev), "c": torch.from_numpy(c[None]).to(dev), "plan": _oflk.Plan(0, 1, H, W, L, 5, K),
+             "stream": torch.cuda.Stream(device=dev), "want": oracle.lucas_kanade_pyramidal(p, c, L, 5, K)}
+        d["u"], d["v"] = torch.empty_like(d["p"]), torch.empty_like(d["p"])
+        cases.append(d)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(d):
+        try:
+            for _ in range(40):
+                d["plan"].pyramidal(d["p"].data_ptr(), d["c"].data_ptr(), d["u"].data_ptr(), d["v"].data_ptr(), d["stream"].cuda_stream)
+            d["stream"].synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append(f"{type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=(d,)) for d in cases]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads) and not errors, errors
+    for d in cases:
+        assert np.array_equal(d["u"].cpu().numpy()[0], d["want"][0]) and np.array_equal(d["v"].cpu().numpy()[0], d["want"][1])
+        d["plan"].close()
