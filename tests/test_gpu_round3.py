@@ -435,3 +435,38 @@ def test_two_plans_on_two_streams_from_two_threads(oracle):
     for d in cases:
         assert np.array_equal(d["u"].cpu().numpy()[0], d["want"][0]) and np.array_equal(d["v"].cpu().numpy()[0], d["want"][1])
         d["plan"].close()
+
+
+def test_a_pass_captured_into_a_hip_graph_replays_the_same_flow(oracle):
+    """plan calls only enqueue kernels, so a caller may capture one pass into a HIP graph.  Captured on a side
+    stream, replayed three times on new frames written into the same buffers: every replay gives the oracle's flow."""
+    import torch
+
+    import _oflk
+    from oflk_synth import synth_pair
+
+    dev = torch.device("cuda", 0)
+    H, W, L, K = 240, 320, 3, 3
+    prev = torch.empty((2, H, W), dtype=torch.float32, device=dev)
+    curr = torch.empty_like(prev)
+    u, v = torch.empty_like(prev), torch.empty_like(prev)
+    plan = _oflk.Plan(0, 2, H, W, L, 5, K)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)   # warm-up outside the capture
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        pairs = [synth_pair(H, W, pair_index=30 + 2 * rep + b) for b in range(2)]
+        prev.copy_(torch.from_numpy(np.stack([p for p, _ in pairs])))
+        curr.copy_(torch.from_numpy(np.stack([c for _, c in pairs])))
+        u.zero_()
+        v.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for b, (p, c) in enumerate(pairs):
+            ou, ov = oracle.lucas_kanade_pyramidal(p, c, L, 5, K)
+            assert np.array_equal(u[b].cpu().numpy(), ou) and np.array_equal(v[b].cpu().numpy(), ov), f"replay {rep} pair {b}"
+    plan.close()
