@@ -470,3 +470,48 @@ def test_a_pass_captured_into_a_hip_graph_replays_the_same_flow(oracle):
             ou, ov = oracle.lucas_kanade_pyramidal(p, c, L, 5, K)
             assert np.array_equal(u[b].cpu().numpy(), ou) and np.array_equal(v[b].cpu().numpy(), ov), f"replay {rep} pair {b}"
     plan.close()
+
+
+def test_shims_accept_any_array_layout_and_dtype():
+    """INTEGRATION.md data contract: the drop-in functions convert whatever they are handed to C-contiguous float32 (or
+    keep uint8) and never write to their inputs: strided views, Fortran order, float64 and integer arrays holding the same
+    values give the results of the contiguous float32 arrays."""
+    import lucas_kanade_core as K
+    import lucas_kanade_pyramidal as P
+    from oflk_synth import synth_flow, synth_pair
+
+    H, W = 150, 210
+    p, c = synth_pair(H, W, pair_index=40)
+    fu, fv = synth_flow(H, W, seed=3)
+    big_p, big_c = np.zeros((2 * H, 2 * W), np.float32), np.zeros((2 * H, 2 * W), np.float32)
+    big_p[::2, ::2], big_c[::2, ::2] = p, c
+    forms = {
+        "strided view": (big_p[::2, ::2], big_c[::2, ::2]),
+        "fortran order": (np.asfortranarray(p), np.asfortranarray(c)),
+        "float64": (p.astype(np.float64), c.astype(np.float64)),
+        "int32": (p.astype(np.int32), c.astype(np.int32)),
+        "uint8": (p.astype(np.uint8), c.astype(np.uint8)),
+        "lists": (p.tolist(), c.tolist()),
+    }
+    want_s = K.lucas_kanade_single_scale(p, c, 5)
+    want_p = P.lucas_kanade_pyramidal(p, c, 3, 5, 2)
+    want_g = K.compute_gradients(p, c)
+    want_y = P.build_gaussian_pyramid(p, 3)
+    for name, (a, b) in forms.items():
+        keep = (np.array(a, copy=True), np.array(b, copy=True))
+        for got, want in ((K.lucas_kanade_single_scale(a, b, 5), want_s), (P.lucas_kanade_pyramidal(a, b, 3, 5, 2), want_p),
+                          (K.compute_gradients(a, b), want_g), (P.build_gaussian_pyramid(a, 3), want_y)):
+            assert len(got) == len(want) and all(np.array_equal(x, y) for x, y in zip(got, want)), name
+        assert np.array_equal(np.asarray(a), keep[0]) and np.array_equal(np.asarray(b), keep[1]), f"{name}: input written"
+    # flows and gradients in other layouts
+    want_w = P.warp_image(c, fu, fv)
+    assert np.array_equal(P.warp_image(np.asfortranarray(c), fu.astype(np.float64).astype(np.float32)[:, :], np.asfortranarray(fv)), want_w)
+    want_u = P.upsample_flow(fu[:75, :105].copy(), fv[:75, :105].copy(), (H, W))
+    got_u = P.upsample_flow(fu[:75, :105], fv[:75, :105], (H, W))        # non-contiguous slices
+    assert all(np.array_equal(x, y) for x, y in zip(got_u, want_u))
+    ix, iy, it = want_g
+    want_f = K.lucas_kanade_from_gradients(ix, iy, it, 5)
+    got_f = K.lucas_kanade_from_gradients(np.asfortranarray(ix), iy[:, :], np.asfortranarray(it), 5)
+    assert all(np.array_equal(x, y) for x, y in zip(got_f, want_f))
+    for out in (*want_s, *want_p):
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.shape == (H, W)
