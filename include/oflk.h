@@ -240,6 +240,7 @@ int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, fl
  * the plan's own pyramid. */
 #define OFLK_ARITH_EXACT 0
 #define OFLK_ARITH_CONTRACTED 1
+#define OFLK_ARITH_TOLERANT 2
 int oflk_plan_set_arithmetic(oflk_plan *plan, int mode);
 
 /* Per-kernel timing with HIP events on the launch stream.  While enabled, every

@@ -7,6 +7,7 @@
 // There is deliberately no CPU path in this library: with no usable GPU every
 // compute entry point returns OFLK_ERR_NO_DEVICE.
 #include "oflk_kernels.hpp"
+#include "oflk_stream.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -379,6 +380,52 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     return OFLK_OK;
 }
 
+// k_lks (oflk_stream.hpp): the streaming form of the 5x5 kernel, for passes whose window sums need not be in NumPy's
+// order (the tolerant mode's fine levels; single-scale on integer-valued frames, where any order is exact).  One wave
+// per (strip of 120 output columns, segment of Hs rows); segments are sized so that the launch is a whole number of
+// rounds of the chip's wave slots at the kernel's occupancy, ~64 rows or more each (a segment pays 6 extra rows).
+template <int MODE>
+int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int B, bool u8, int warp)
+{
+    LkArgs a = a_in;
+    a.B = B;
+    Prof pr(plan, s, cls);
+    const long strips = ((long)a.W + kLksOutW - 1) / kLksOutW * B;
+    const long slots = 256 * 4 * OFLK_LKS_WAVES;   // wave slots of the chip at the kernel's occupancy
+    long segs = ((long)a.H + 63) / 64;
+    const double rounds = (double)(strips * segs) / (double)slots;
+    if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
+    else segs = std::max(segs, std::min(slots / std::max<long>(strips, 1), std::max<long>(1, a.H / 40)));   // fill the one round, >= 40 rows each
+    segs = std::min<long>(segs, std::max<long>(1, a.H / 8));
+    a.Hs = (int)(((long)a.H + segs - 1) / segs);
+    a.segs = (a.H + a.Hs - 1) / a.Hs;
+    const long nwave = strips * a.segs;
+    dim3 grid((unsigned)((nwave + 3) / 4)), block(256);
+    auto al = [](const void *q, unsigned m) { return (reinterpret_cast<uintptr_t>(q) & (m - 1)) == 0; };
+    const bool frames_ok = u8 ? (al(a.prev, 2) && al(a.curr, 2)) : (al(a.prev, 8) && al(a.curr, 8));
+    const bool vec = (a.W & 1) == 0 && a.W >= 2 && frames_ok && al(a.ou, 8) && al(a.ov, 8) &&
+                     (MODE != MODE_ITER || (al(a.fl[0], 16) && al(a.fl[1], 16)));
+#define OFLK_LAUNCH_LKS(WV)                                                                                   \
+    do {                                                                                                      \
+        if (u8) {                                                                                             \
+            if (vec) hipLaunchKernelGGL((k_lks<MODE, true, WV, unsigned char>), grid, block, 0, s, a);        \
+            else hipLaunchKernelGGL((k_lks<MODE, false, WV, unsigned char>), grid, block, 0, s, a);           \
+        } else {                                                                                              \
+            if (vec) hipLaunchKernelGGL((k_lks<MODE, true, WV, float>), grid, block, 0, s, a);                \
+            else hipLaunchKernelGGL((k_lks<MODE, false, WV, float>), grid, block, 0, s, a);                   \
+        }                                                                                                     \
+    } while (0)
+    if constexpr (MODE == MODE_ITER) {
+        if (warp == WARP_LERP64) OFLK_LAUNCH_LKS(WARP_LERP64);
+        else OFLK_LAUNCH_LKS(WARP_SCIPY);
+    } else {
+        OFLK_LAUNCH_LKS(WARP_SCIPY);
+    }
+#undef OFLK_LAUNCH_LKS
+    HIP_TRY(hipGetLastError());
+    return OFLK_OK;
+}
+
 inline dim3 grid2d(int W, int H, int n) { return dim3((W + 63) / 64, (H + 3) / 4, n); }
 // k_resample: 4 outputs per thread along x
 inline dim3 grid_resample(int W, int H, int n) { return dim3((W + 255) / 256, (H + 3) / 4, n); }
@@ -488,7 +535,7 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
         for (int k = 0; k <= 8; k++) a.w[k] = gauss.w[k];
         dim3 grid((wo + kPTW - 1) / kPTW, (ho + kPTH - 1) / kPTH, nimg);
         Prof pr(plan, s, KC_PYR_FUSED);
-        const bool fma = plan && plan->arith == OFLK_ARITH_CONTRACTED;   // opt-in; never the default
+        const bool fma = plan && plan->arith != OFLK_ARITH_EXACT;   // opt-in (contracted / tolerant); never the default
         if (extra && extra->u8) {
             if (fma) hipLaunchKernelGGL((k_pyr_down<unsigned char, true>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_pyr_down<unsigned char, false>), grid, dim3(256), 0, s, a);
@@ -514,10 +561,12 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
     }
     {
         Prof pr(plan, s, KC_BLUR);
-        hipLaunchKernelGGL((k_blur<0>), grid2d(w, h, nimg), dim3(256), 0, s, in, tmpA, h, w, gauss);
+        const bool fma = plan && plan->arith != OFLK_ARITH_EXACT;   // the unfused chain keeps the plan's arithmetic
+        if (fma) hipLaunchKernelGGL((k_blur<0, true>), grid2d(w, h, nimg), dim3(256), 0, s, in, tmpA, h, w, gauss);
+        else hipLaunchKernelGGL((k_blur<0, false>), grid2d(w, h, nimg), dim3(256), 0, s, in, tmpA, h, w, gauss);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((k_blur<1>), grid2d(w, h, nimg), dim3(256), 0, s, (const float *)tmpA, tmpB, h,
-                           w, gauss);
+        if (fma) hipLaunchKernelGGL((k_blur<1, true>), grid2d(w, h, nimg), dim3(256), 0, s, (const float *)tmpA, tmpB, h, w, gauss);
+        else hipLaunchKernelGGL((k_blur<1, false>), grid2d(w, h, nimg), dim3(256), 0, s, (const float *)tmpA, tmpB, h, w, gauss);
         HIP_TRY(hipGetLastError());
     }
     ResampleArgs r{};
@@ -533,7 +582,8 @@ int launch_pyr_down(oflk_plan *plan, const GaussW &gauss, hipStream_t s, const f
     r.vec_store = (wo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     {
         Prof pr(plan, s, KC_RESAMPLE);
-        hipLaunchKernelGGL(k_resample<1>, grid_resample(wo, ho, nimg), dim3(256), 0, s, r);
+        if (plan && plan->arith != OFLK_ARITH_EXACT) hipLaunchKernelGGL((k_resample<1, true>), grid_resample(wo, ho, nimg), dim3(256), 0, s, r);
+        else hipLaunchKernelGGL((k_resample<1, false>), grid_resample(wo, ho, nimg), dim3(256), 0, s, r);
     }
     HIP_TRY(hipGetLastError());
     return OFLK_OK;
@@ -879,7 +929,10 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
             a.conv_thr = conv_threshold((double)n);
             a.level = l; a.iter = k; a.L = L; a.K = p->Kc();
             a.H = h; a.W = w;
-            rc = launch_lk<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, p->hw, a, B, u8 && l == L - 1);
+            // tolerant mode: the two finest levels take the streaming kernel (order-free window sums, fused-lerp warp)
+            const bool stream = p->arith == OFLK_ARITH_TOLERANT && p->hw == 2 && l >= L - 2 && h > 4 && w > 4;
+            if (stream) rc = launch_lks<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, a, B, u8 && l == L - 1, WARP_LERP64);
+            else rc = launch_lk<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, p->hw, a, B, u8 && l == L - 1);
             if (rc) return rc;
         }
     }
@@ -1158,8 +1211,8 @@ OFLK_API int oflk_plan_read_level_flow(oflk_plan *p, int level, int pair, float 
 OFLK_API int oflk_plan_set_arithmetic(oflk_plan *p, int mode)
 {
     if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
-    if (mode != OFLK_ARITH_EXACT && mode != OFLK_ARITH_CONTRACTED)
-        return fail(OFLK_ERR_INVALID, "arithmetic mode must be OFLK_ARITH_EXACT (0) or OFLK_ARITH_CONTRACTED (1), got %d", mode);
+    if (mode != OFLK_ARITH_EXACT && mode != OFLK_ARITH_CONTRACTED && mode != OFLK_ARITH_TOLERANT)
+        return fail(OFLK_ERR_INVALID, "arithmetic mode must be OFLK_ARITH_EXACT (0), OFLK_ARITH_CONTRACTED (1) or OFLK_ARITH_TOLERANT (2), got %d", mode);
     p->arith = mode;
     return OFLK_OK;
 }

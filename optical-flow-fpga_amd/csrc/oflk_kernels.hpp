@@ -381,6 +381,12 @@ struct LkArgs {
     // block; nseg = 0 means one tile per block (plain XCD tile order)
     int nseg;
     unsigned short seg_row[kMaxSegs + 1];
+    // streaming kernel k_lks (oflk_stream.hpp): rows per segment, segments per strip
+    int Hs, segs;
+    // SINGLE on integer-valued frames: one byte per 64 x 24 tile, [B][tiles_y][tiles_x].  k_lks sets the flag of a tile
+    // in which its order-free window sums may differ from NumPy's; k_lkw launched with the same pointer redoes exactly
+    // the flagged tiles (and clears their flags).  nullptr: no flags / every tile.
+    unsigned char *redo;
 #ifdef OFLK_STAMPS
     unsigned *stamps;   // diagnostic build only: [block][wave][16] cycle sums per code section
 #endif
@@ -1016,6 +1022,11 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         tile_y_first = t / tiles_x;
         tile_x = t - tile_y_first * tiles_x;
         ntile = 1;
+        if (MODE == MODE_SINGLE && a.redo != nullptr) {   // uniform: redo pass after k_lks, flagged tiles only
+            if (!a.redo[tile]) return;
+            __syncthreads();                               // every thread has read the flag
+            if (threadIdx.x == 0) a.redo[tile] = 0;
+        }
     } else {
         // XCD x (block ids x, x+8, ...) owns the column strips [x*S/8, (x+1)*S/8) and runs
         // their segments longest first (seg_row is built that way), so the blocks still in
@@ -1584,7 +1595,8 @@ __device__ __forceinline__ int reflect_idx(int i, int n)
 }
 
 // AXIS 0: along y (columns), AXIS 1: along x (rows)
-template <int AXIS>
+// FMA: the opt-in contracted form (see k_pyr_down): the multiply and the add of a tap fused
+template <int AXIS, bool FMA = false>
 __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ in, float *__restrict__ out,
                                               int H, int W, GaussW g)
 {
@@ -1602,8 +1614,12 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ in, floa
     double tmp = at(c) * g.w[0];
     for (int k = g.radius; k >= 1; k--) {
         double s = at(c - k) + at(c + k);
-        double m = s * g.w[k];
-        tmp = tmp + m;
+        if constexpr (FMA) {
+            tmp = __builtin_fma(s, g.w[k], tmp);
+        } else {
+            double m = s * g.w[k];
+            tmp = tmp + m;
+        }
     }
     out[(size_t)blockIdx.z * plane + (size_t)y * W + x] = (float)tmp;
 }
@@ -1635,7 +1651,8 @@ struct ResampleArgs {
 // One thread produces 4 horizontally adjacent outputs of NP planes: the row taps and
 // weights are computed once, all 16*NP tap loads are issued before any arithmetic, and
 // the stores are 16 bytes per lane.  grid = (ceil(Wo/256), ceil(Ho/4), nimg), block = 64 x 4.
-template <int NP>
+// FMA: the opt-in contracted form of the tap sum (as stage D of k_pyr_down<PIX, true>), pyramid steps only
+template <int NP, bool FMA = false>
 __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
 {
     const int j0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -1692,10 +1709,17 @@ __global__ __launch_bounds__(256) void k_resample(ResampleArgs a)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             double acc = 0.0, c;
-            c = (double)t[p][k][0]; c = c * wy0; c = c * wx0[k]; acc = acc + c;
-            c = (double)t[p][k][1]; c = c * wy0; c = c * wx1[k]; acc = acc + c;
-            c = (double)t[p][k][2]; c = c * wy1; c = c * wx0[k]; acc = acc + c;
-            c = (double)t[p][k][3]; c = c * wy1; c = c * wx1[k]; acc = acc + c;
+            if constexpr (FMA) {
+                c = (double)t[p][k][0]; c = c * wy0; acc = c * wx0[k];
+                c = (double)t[p][k][1]; c = c * wy0; acc = __builtin_fma(c, wx1[k], acc);
+                c = (double)t[p][k][2]; c = c * wy1; acc = __builtin_fma(c, wx0[k], acc);
+                c = (double)t[p][k][3]; c = c * wy1; acc = __builtin_fma(c, wx1[k], acc);
+            } else {
+                c = (double)t[p][k][0]; c = c * wy0; c = c * wx0[k]; acc = acc + c;
+                c = (double)t[p][k][1]; c = c * wy0; c = c * wx1[k]; acc = acc + c;
+                c = (double)t[p][k][2]; c = c * wy1; c = c * wx0[k]; acc = acc + c;
+                c = (double)t[p][k][3]; c = c * wy1; c = c * wx1[k]; acc = acc + c;
+            }
             float r = inside[k] ? (float)acc : 0.0f;
             if (a.apply_scale) r = r * a.scale[p];
             res[p][k] = r;

@@ -1,0 +1,409 @@
+// oflk_stream.hpp -- k_lks: the streaming form of the fused Lucas-Kanade kernel (5x5 window), gfx950.
+//
+// k_lkw (oflk_kernels.hpp) stages tiles in LDS because NumPy's summation order of a 5x5 window
+// (lucas_kanade_core.py:115-119) has no separable form.  Where the order of the 25 additions is free, the window
+// sums separate -- five rows added vertically, five columns horizontally -- and the kernel can STREAM: no LDS, no
+// barrier.  A wave owns a strip of 128 image columns, two per lane, and walks down a segment of rows:
+//   per row   coalesced loads of prev and the flow (three rows ahead); the bilinear gathers of `curr` for the row
+//             after this one are issued before this row's arithmetic and used after it
+//             warp (ITER), frame average, It; Sobel/8 of the row above in convolve2d's own tap order, from three
+//             average rows held in registers, the x-neighbours through DPP wave shifts (the gradients are the
+//             reference's, bit for bit)
+//             five products; vertical 5-sums  ((p[o-2] + p[o-1]) + (p[o] + p[o+1])) + p[o+2]  as three adds per row
+//             and plane from a ring of pair sums; horizontal 5-sums by four wave shifts per plane:
+//                 even column c:  ((V[c-2] + V[c-1]) + (V[c] + V[c+1])) + V[c+2]
+//                 odd column c:   (V[c-2] + (V[c-1] + V[c])) + (V[c+1] + V[c+2])
+//             2x2 solve in the reference's operation sequence (IEEE division), flow += d, |d| sums
+// A wave produces 120 of its 128 columns (window halo 2 + Sobel halo 1, rounded to lane pairs); a segment of Hs
+// rows costs 6 extra rows.
+//
+// Two uses:
+//  * OFLK_ARITH_TOLERANT (opt-in): the iterations of the two finest pyramid levels.  The sums are NOT in NumPy's
+//    order, so flows are close to, not equal to, the reference's: oracle/oflk_tolerant_model.c states this arithmetic
+//    on the CPU, tests hold this kernel to it bit for bit and the model to the reference-made dense flows within
+//    the 1e-4 bar (tools/experiments/fast_mode_ablation.py: what each cell of the pass costs).
+//  * MODE_SINGLE on integer-valued frames (EXACT): gradients are multiples of 1/16 there, products of 2^-8 (2^-4
+//    with It), so while a window's sums stay below 2^16 every partial sum is exact in any order and the separable
+//    sums ARE NumPy's.  A wave checks Sxx, Syy < 2^15 on every window it solves and flags the 64 x 24 tiles where
+//    that fails; the tile kernel k_lkw then redoes exactly those tiles (k_lkw's `redo` list).
+#pragma once
+
+namespace oflk {
+
+enum { WARP_SCIPY = 0, WARP_LERP64 = 1 };
+
+// fused form of the bilinear sample: three lerps, each one fma.  The fp64 result differs from SciPy's 15-operation
+// sum by a few 1e-16 relative before it is rounded to float32 where SciPy rounds.
+__device__ __forceinline__ float lerp64_finish(const LeanFrac &t, PairF r0, PairF r1)
+{
+    const double a = (double)r0.a, b = (double)r0.b, c = (double)r1.a, d = (double)r1.b;
+    const double top = __builtin_fma(t.rx, b - a, a), bot = __builtin_fma(t.rx, d - c, c);
+    const double r = __builtin_fma(t.ry, bot - top, top);
+    return t.inside ? (float)r : 0.0f;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float wshift(float v)   // 0x138: lane i takes lane i-1's value; 0x130: lane i+1's
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+constexpr int kLksOutW = 120;   // output columns per wave
+#ifndef OFLK_LKS_PFROWS
+#define OFLK_LKS_PFROWS 0     // the prefetch of `curr` runs this many rows ahead of the coalesced loads
+#endif
+#ifndef OFLK_LKS_WAVES
+#define OFLK_LKS_WAVES 4      // waves per SIMD the kernel's register count allows (the host sizes segments with it)
+#endif
+
+// Integer-valued frames, MODE_SINGLE: a window whose Sxx or Syy reaches this bound may have rounded a partial sum
+constexpr float kLksExactBound = 32768.0f;
+
+template <int MODE, bool VEC, int WARPV, class PIX = float>
+__global__ __launch_bounds__(256) void k_lks(LkArgs a)
+{
+    static_assert(MODE == MODE_SINGLE || MODE == MODE_ITER, "gradient planes take the tile kernel");
+    constexpr int HW = 2, R = HW + 1, HL = 2, OUTW = kLksOutW, WPB = 4;
+    constexpr int SHR = 0x138, SHL = 0x130;   // DPP wave_shr:1 / wave_shl:1
+    const int lane = threadIdx.x & 63;
+    const int H = a.H, W = a.W;
+    const int strips = (W + OUTW - 1) / OUTW;
+    const int per_pair = strips * a.segs;
+    const int nwave = per_pair * a.B;
+    const int nblk = (nwave + WPB - 1) / WPB;
+    const int task = __builtin_amdgcn_readfirstlane(xcd_tile_index(blockIdx.x, nblk) * WPB + (int)(threadIdx.x >> 6));
+    if (task >= nwave) return;
+    const int b = task / per_pair;
+    const int tt = task - b * per_pair;
+    const int seg = tt / strips, strip = tt - seg * strips;
+    int sel = 0;
+    if (MODE == MODE_ITER) {
+        const LevelState st = lk_level_state(a.acc, b, a.level, a.iter, a.L, a.K, a.conv_thr);
+        if (st.done) return;
+        sel = st.executed & 1;
+    }
+    const int xw = strip * OUTW - 2 * HL;          // first column of the wave (uniform, even)
+    const int x = xw + 2 * lane;                   // the lane's low column (even)
+    const int Wm1 = W - 1, Hm1 = H - 1;
+    const int c0 = min(max(x, 0), Wm1), c1 = min(max(x + 1, 0), Wm1);   // "symm" ring: the edge column repeats
+    const int cp = min(max(x, 0), max(W - 2, 0));                       // VEC: first column of the lane's pair (even)
+    const bool dup_lo = x < 0, dup_hi = x >= W;
+    const int ys = seg * a.Hs, ye = min(ys + a.Hs, H);
+    const size_t plane = (size_t)H * (size_t)W;
+    const PIX *__restrict__ prev = reinterpret_cast<const PIX *>(a.prev) + (size_t)b * plane;
+    const PIX *__restrict__ curr = reinterpret_cast<const PIX *>(a.curr) + (size_t)b * plane;
+    const float2 *__restrict__ fin = MODE == MODE_ITER ? a.fl[sel] + (size_t)b * plane : nullptr;
+    float2 *__restrict__ fout = MODE == MODE_ITER ? a.fl[1 - sel] + (size_t)b * plane : nullptr;
+    float *__restrict__ ou = a.ou + (size_t)b * plane;
+    float *__restrict__ ov = a.ov + (size_t)b * plane;
+    const bool planar = MODE != MODE_ITER || a.planar_out != 0;   // uniform
+    const bool lane_out = lane >= HL && lane < 64 - HL;
+    const bool in0 = x >= HW && x < W - HW, in1 = x + 1 >= HW && x + 1 < W - HW;   // columns with a full window
+
+    auto row_e = [&](int r) { return (unsigned)(min(max(r, 0), Hm1) * W); };   // element offset of the (clamped) row
+    // The lanes of a border strip that lie outside the frame repeat its edge column ("symm"): selects on the loaded value
+    // WHERE IT IS USED (fix_*), behind an optimisation fence -- written as a conditional next to the load, the compiler
+    // splits the wide load in two and branches around the second half, with a full wait after each.  `edge` is
+    // wave-uniform: interior strips skip the selects.
+    const bool edge = xw < 0 || xw + 128 > W;
+    auto opaque = [](float &v) { asm volatile("" : "+v"(v)); };
+    auto fix_pix2 = [&](float2 &r) {
+        if constexpr (VEC) {
+            opaque(r.x);
+            opaque(r.y);
+            if (edge) {
+                r.x = dup_hi ? r.y : r.x;
+                r.y = dup_lo ? r.x : r.y;
+            }
+        }
+    };
+    auto fix_flow2 = [&](float4 &w) {
+        if constexpr (VEC) {
+            opaque(w.x);
+            opaque(w.y);
+            opaque(w.z);
+            opaque(w.w);
+            if (edge) {
+                w.x = dup_hi ? w.z : w.x;
+                w.y = dup_hi ? w.w : w.y;
+                w.z = dup_lo ? w.x : w.z;
+                w.w = dup_lo ? w.y : w.w;
+            }
+        }
+    };
+    // two pixels of a frame row (VEC: raw, see fix_pix2)
+    auto load_pix2 = [&](const PIX *base, unsigned rowe) -> float2 {
+        if constexpr (VEC) {
+            const PairF w = ld_pix_pair<PIX>(scalar_ptr(base + rowe), (unsigned)cp);
+            return make_float2(w.a, w.b);
+        } else {
+            const PIX *rp = scalar_ptr(base + rowe);
+            return make_float2(ld_pix<PIX>(rp, (unsigned)c0), ld_pix<PIX>(rp, (unsigned)c1));
+        }
+    };
+    // {u0, v0, u1, v1} of the two pixels (VEC: raw, see fix_flow2)
+    auto load_flow2 = [&](const float2 *base, unsigned rowe) -> float4 {
+        if constexpr (VEC) {
+            return ld_off<float4>(scalar_ptr(base + rowe), (unsigned)cp * 8u);
+        } else {
+            const float2 *rp = scalar_ptr(base + rowe);
+            const float2 f0 = ld_off<float2>(rp, (unsigned)c0 * 8u), f1 = ld_off<float2>(rp, (unsigned)c1 * 8u);
+            return make_float4(f0.x, f0.y, f1.x, f1.y);
+        }
+    };
+
+    const LeanGeom lg = lean_geom(H, W);
+    const double gxd0 = (double)c0, gxd1 = (double)c1;
+
+    // ---- pipeline state ------------------------------------------------------------------------------------
+    constexpr int LD = 3;                 // coalesced loads run LD rows ahead of the arithmetic
+    float2 Pr[LD];                        // prev rows
+    float2 Qr[LD];                        // SINGLE: curr rows
+    float4 Fr[LD];                        // ITER: flow rows
+    float Cr[LD];                         // ITER: prefetch of `curr` (see issue_loads)
+    LeanFrac gt[2];                       // ITER: the gathers in flight (row r + 1)
+    PairF g0[2], g1[2];
+    // frame-average rows {lo, hi, left neighbour of lo, right neighbour of hi}, ring of three
+    float Alo[3], Ahi[3], AL[3], AR[3];
+    float2 it1 = make_float2(0.0f, 0.0f);                        // It of the row above
+    float P1[5][2], Qv[3][5][2];                                 // previous product row; ring of vertical pair sums
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        Alo[j] = Ahi[j] = AL[j] = AR[j] = 0.0f;
+#pragma unroll
+        for (int pl = 0; pl < 5; pl++) Qv[j][pl][0] = Qv[j][pl][1] = 0.0f;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 5; pl++) P1[pl][0] = P1[pl][1] = 0.0f;
+    float su = 0.0f, sv = 0.0f;           // |d| sums of the current three rows
+    double dsu = 0.0, dsv = 0.0;          // ... of the segment
+    unsigned inexact = 0u;                // SINGLE: a solved window reached kLksExactBound in one of the last 24 rows
+    float4 pf_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // ITER: the flow of the next output row
+
+    const int r0 = ys - R;                // first average row
+    const int n_it = (ye - ys) + 2 * R;   // average rows r0 .. ye + R - 1
+
+    float touch = 0.0f;                   // ITER: keeps the prefetch loads of `curr` alive (never part of a result)
+    auto issue_loads = [&](int slot, int r) {
+        const unsigned rowe = row_e(r);
+        Pr[slot] = load_pix2(prev, rowe);
+        if constexpr (MODE == MODE_ITER) {
+            Fr[slot] = load_flow2(fin, rowe);
+            // the warp's gathers two rows later find `curr` in the L2 instead of paying the HBM's latency inside the row loop:
+            // a coalesced read of the same row brings its lines in (flows of a few pixels stay inside them)
+            Cr[slot] = ld_pix<PIX>(scalar_ptr(curr + row_e(r + OFLK_LKS_PFROWS)), (unsigned)c0);
+        } else {
+            Qr[slot] = load_pix2(curr, rowe);
+        }
+    };
+    // coordinates and gathers of row r (its flow is Fr[slot])
+    auto issue_gathers = [&](int slot, int r) {
+        if constexpr (MODE == MODE_ITER) {
+            const int gy = min(max(r, 0), Hm1);
+            const double yd = uint_to_f64_bits(gy);   // scalar ALU: the row is wave-uniform
+            float4 f = Fr[slot];
+            fix_flow2(f);
+            // int64 + float32 -> float64, as the reference (lucas_kanade_pyramidal.py:88-95)
+            gt[0] = lean_frac_at(lg, yd + (double)f.y, gxd0 + (double)f.x);
+            gt[1] = lean_frac_at(lg, yd + (double)f.w, gxd1 + (double)f.z);
+            lean_load<false, PIX>(lg, curr, gt[0], g0[0], g1[0]);
+            lean_load<false, PIX>(lg, curr, gt[1], g0[1], g1[1]);
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < LD; k++) issue_loads(k, r0 + k);
+    issue_gathers(0, r0);
+
+    for (int i0 = 0; i0 < n_it; i0 += 3) {
+        static_for(std::make_integer_sequence<int, 3>{}, [&](auto jc) {
+            constexpr int j = decltype(jc)::value;            // = i mod 3: ring slots are static
+            const int i = i0 + j;   // (the last trip may run up to two rows past the segment: clamped loads, no stores)
+            const int r = r0 + i;
+            // ---- second frame of row r (warped if ITER), frame average, It --------------------------------
+            float2 p = Pr[j];
+            fix_pix2(p);
+            if constexpr (MODE == MODE_ITER) touch = fmaxf(touch, Cr[j]);
+            float2 q;
+            if constexpr (MODE == MODE_ITER) {
+                if constexpr (WARPV == WARP_LERP64) {
+                    q.x = lerp64_finish(gt[0], g0[0], g1[0]);
+                    q.y = lerp64_finish(gt[1], g0[1], g1[1]);
+                } else {
+                    q.x = lean_finish(gt[0], g0[0], g1[0]);
+                    q.y = lean_finish(gt[1], g0[1], g1[1]);
+                }
+            } else {
+                q = Qr[j];
+                fix_pix2(q);
+            }
+            const int o = r - R;                               // the output row this iteration completes
+            const bool o_live = o >= ys && o < ye;             // uniform: the pipeline is full and the row is the segment's
+            __builtin_amdgcn_sched_barrier(0);                 // the waits above come before the issues below
+            // Vector-memory results return in issue order, so a wait for one load is a wait for every load issued before
+            // it: the loads of an iteration go out oldest-needed first -- the flow of the NEXT output row (flow += d,
+            // lucas_kanade_pyramidal.py:209-210, needs it again: an L2 hit), the gathers of the next row, the coalesced
+            // loads three rows ahead -- and every wait leaves the younger ones in flight.
+            float4 pf = pf_next;   // (lane_out lanes of a VEC launch lie inside the frame: no fix-up needed)
+            if constexpr (MODE == MODE_ITER) {
+                if (o + 1 >= ys) pf_next = load_flow2(fin, row_e(o + 1));
+                issue_gathers((j + 1) % 3, r + 1);            // used by the next row, after this row's arithmetic
+            }
+            issue_loads(j, r + LD);
+            __builtin_amdgcn_sched_barrier(0);
+            // (prev + curr) / 2.0 and prev - curr, lucas_kanade_core.py:36, :43
+            const float s0 = p.x + q.x, s1 = p.y + q.y;
+            Alo[j] = s0 * 0.5f;
+            Ahi[j] = s1 * 0.5f;
+            const float2 itn = make_float2(p.x - q.x, p.y - q.y);
+            AL[j] = wshift<SHR>(Ahi[j]);                       // column 2l - 1
+            AR[j] = wshift<SHL>(Alo[j]);                       // column 2l + 2
+            // ---- Sobel/8 of row r - 1 in convolve2d's tap order (same operations as k_lkw's) ----------------
+            constexpr int jm = (j + 1) % 3, jz = (j + 2) % 3, jp = j;   // rows r-2, r-1, r
+            auto sobel = [](float a_mm, float a_m0, float a_mp, float a_0m, float a_0p, float a_pm, float a_p0, float a_pp,
+                            float &ix, float &iy) {
+                ix = a_pp * -0.125f;
+                iy = a_pp * -0.125f;
+                ix = fmaf(a_pm, 0.125f, ix);
+                ix = fmaf(a_0p, -0.25f, ix);
+                ix = fmaf(a_0m, 0.25f, ix);
+                ix = fmaf(a_mp, -0.125f, ix);
+                ix = fmaf(a_mm, 0.125f, ix);
+                iy = fmaf(a_p0, -0.25f, iy);
+                iy = fmaf(a_pm, -0.125f, iy);
+                iy = fmaf(a_mp, 0.125f, iy);
+                iy = fmaf(a_m0, 0.25f, iy);
+                iy = fmaf(a_mm, 0.125f, iy);
+            };
+            float ix[2], iy[2];
+            sobel(AL[jm], Alo[jm], Ahi[jm], AL[jz], Ahi[jz], AL[jp], Alo[jp], Ahi[jp], ix[0], iy[0]);
+            sobel(Alo[jm], Ahi[jm], AR[jm], Alo[jz], AR[jz], Alo[jp], Ahi[jp], AR[jp], ix[1], iy[1]);
+            const float itv[2] = {it1.x, it1.y};
+            it1 = itn;
+            // ---- products of row g = r - 1, vertical sums of output row o = g - 2 -----------------------------
+            float V[5][2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                float pr[5];
+                pr[0] = ix[c] * ix[c];
+                pr[1] = iy[c] * iy[c];
+                pr[2] = ix[c] * iy[c];
+                pr[3] = ix[c] * itv[c];
+                pr[4] = iy[c] * itv[c];
+#pragma unroll
+                for (int pl = 0; pl < 5; pl++) {
+                    // ring slot of the pair sum q[g'] = p[g'] + p[g'+1]: the iteration that formed it, mod 3
+                    V[pl][c] = (Qv[(j + 2) % 3][pl][c] + Qv[(j + 1) % 3][pl][c]) + pr[pl];   // (q[g-4] + q[g-2]) + p[g]
+                    Qv[(j + 2) % 3][pl][c] = P1[pl][c] + pr[pl];                              // q[g-1]
+                    P1[pl][c] = pr[pl];
+                }
+            }
+            // ---- horizontal sums, solve, flow += d ------------------------------------------------------------
+            float S[5][2];
+#pragma unroll
+            for (int pl = 0; pl < 5; pl++) {
+                const float lo = V[pl][0], hi = V[pl][1];
+                const float pp = lo + hi;
+                const float X = wshift<SHR>(pp) + pp;          // (V[c-2] + V[c-1]) + (V[c] + V[c+1])
+                S[pl][0] = X + wshift<SHL>(lo);                // ... + V[c+2]
+                const float Y = wshift<SHR>(hi) + pp;          // V[c-2] + (V[c-1] + V[c])      (c = the odd column)
+                S[pl][1] = Y + wshift<SHL>(pp);                // ... + (V[c+1] + V[c+2])
+            }
+            const bool oky = o >= HW && o < H - HW;            // borders stay 0 (lucas_kanade_core.py:101-108)
+            float du[2], dv[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                float uu, vv;
+                lk_solve(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], uu, vv);
+                const bool interior = oky && (c ? in1 : in0);
+                du[c] = interior ? uu : 0.0f;
+                dv[c] = interior ? vv : 0.0f;
+                if constexpr (MODE == MODE_SINGLE) {
+                    if (interior && lane_out && o_live && !(S[0][c] < kLksExactBound && S[1][c] < kLksExactBound)) inexact |= 1u;
+                }
+                if constexpr (MODE == MODE_ITER) {
+                    if (lane_out && o_live) {   // halo lanes repeat their neighbours' pixels
+                        su += fabsf(du[c]);
+                        sv += fabsf(dv[c]);
+                    }
+                }
+            }
+            if (lane_out && o_live) {
+                const unsigned orow = (unsigned)(o * W);
+                float2 ru = make_float2(du[0], du[1]), rv = make_float2(dv[0], dv[1]);
+                if constexpr (MODE == MODE_ITER) {
+                    ru.x = pf.x + ru.x; ru.y = pf.z + ru.y;
+                    rv.x = pf.y + rv.x; rv.y = pf.w + rv.y;
+                }
+                if constexpr (VEC) {
+                    if (x < W) {   // x >= 0 for output lanes; W even: the pair is inside
+                        if (planar) {
+                            st_off<float2>(ou + orow, 4u * (unsigned)x, ru);
+                            st_off<float2>(ov + orow, 4u * (unsigned)x, rv);
+                        } else {
+                            st_off<float4>(fout + orow, 8u * (unsigned)x, make_float4(ru.x, rv.x, ru.y, rv.y));
+                        }
+                    }
+                } else {
+                    if (x < W) {
+                        if (planar) {
+                            st_off<float>(ou + orow, 4u * (unsigned)x, ru.x);
+                            st_off<float>(ov + orow, 4u * (unsigned)x, rv.x);
+                        } else {
+                            st_off<float2>(fout + orow, 8u * (unsigned)x, make_float2(ru.x, rv.x));
+                        }
+                    }
+                    if (x + 1 < W) {
+                        if (planar) {
+                            st_off<float>(ou + orow, 4u * (unsigned)(x + 1), ru.y);
+                            st_off<float>(ov + orow, 4u * (unsigned)(x + 1), rv.y);
+                        } else {
+                            st_off<float2>(fout + orow, 8u * (unsigned)(x + 1), make_float2(ru.y, rv.y));
+                        }
+                    }
+                }
+            }
+            if constexpr (MODE == MODE_SINGLE) {
+                // one flag per 64 x 24 tile of k_lkw's grid (a.redo: [B][tiles_y][tiles_x] bytes): at the last output row of
+                // a tile row and at the end of the segment the lanes that saw an inexact window mark their tiles
+                if (a.redo != nullptr && o_live && (((o + 1) % k5TY) == 0 || o == ye - 1)) {
+                    if (inexact && lane_out && x < W) {
+                        const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
+                        unsigned char *flags = a.redo + ((size_t)b * tiles_y + (size_t)(o / k5TY)) * tiles_x;
+                        flags[x / k5TX] = 1;
+                        flags[min(x + 1, Wm1) / k5TX] = 1;
+                    }
+                    inexact = 0u;
+                }
+            }
+        });
+        if constexpr (MODE == MODE_ITER) {
+            // six fp32 terms per lane, then fp64 (what k_lkw does per thread and tile)
+            dsu += (double)su;
+            dsv += (double)sv;
+            su = 0.0f;
+            sv = 0.0f;
+        }
+    }
+    if constexpr (MODE == MODE_ITER) {
+        // the wave's totals in the accumulators' fixed point: integer adds commute, so neither the lane order here nor the
+        // order of the waves' atomics matters
+        const double cap = kAccBlockMax / 64.0;
+        dsu = dsu < cap ? dsu : cap;   // (also catches NaN)
+        dsv = dsv < cap ? dsv : cap;
+        long long tu = __double2ll_rn(dsu * kAccScale), tv = __double2ll_rn(dsv * kAccScale);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            tu += __shfl_xor(tu, m, 64);
+            tv += __shfl_xor(tv, m, 64);
+        }
+        if (touch == 1.5e38f) tu += 1;   // never true for pixel data; makes `touch` observable
+        if (lane == 0) {
+            unsigned long long *slot = a.acc + acc_index(b, a.level, a.iter, a.L, a.K) + kAccStride * (task & (kAccShards - 1));
+            __hip_atomic_fetch_add(slot + 0, (unsigned long long)tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(slot + 1, (unsigned long long)tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace oflk

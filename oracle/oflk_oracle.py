@@ -27,8 +27,8 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 
 def build(force: bool = False) -> Path:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src = _HERE / "oflk_oracle.c"
-    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+    srcs = [_HERE / "oflk_oracle.c", _HERE / "oflk_tolerant_model.c"]
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(_HERE), "-s", "-B"], check=True)
     return _LIB_PATH
 

@@ -1,0 +1,142 @@
+"""GPU tests of the opt-in within-tolerance arithmetic (OFLK_ARITH_TOLERANT, include/oflk.h).
+
+Two links, each sharp on its own:
+  * HIP == CPU model, bit for bit: oracle/oflk_tolerant_model.c states the tolerant mode's arithmetic operation for operation
+    (fused multiply-adds in the pyramid and in the warp's three lerps, window sums vertical-then-horizontal on the two
+    finest levels); the kernels reproduce it on every shape tried here -- so the mode has no arithmetic of its own to trust.
+  * model (hence HIP) vs THE REFERENCE: mean endpoint error <= 1e-4 (BASELINE.json north_star) against dense flows the
+    reference itself produced (tests/golden/dense_reference_flows.npz, made by make_golden_dense.py importing it): all 13
+    verification patterns and pair 0 of the bench workload at 1920x1080.
+The default (exact) mode is untouched: switching back gives the exact digests again.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # mean endpoint error against the reference's flow, px (north_star)
+
+
+def _epe(u, v, ru, rv):
+    return float(np.mean(np.sqrt((u.astype(np.float64) - ru) ** 2 + (v.astype(np.float64) - rv) ** 2)))
+
+
+def _run(plan, p, c, u8=False):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    tp, tc = torch.from_numpy(p).to(dev), torch.from_numpy(c).to(dev)
+    u = torch.empty(p.shape, dtype=torch.float32, device=dev)
+    v = torch.empty_like(u)
+    (plan.pyramidal_u8 if u8 else plan.pyramidal)(tp.data_ptr(), tc.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+    log, runs = plan.read_log(st)
+    torch.cuda.synchronize()
+    return u.cpu().numpy(), v.cpu().numpy(), log, runs
+
+
+def _model(p, c, L, K):
+    import oflk_tolerant_model as M
+
+    return M.pyramidal(p.astype(np.float32), c.astype(np.float32), M.tolerant_spec(L, K), 5)
+
+
+def _pair(rng, H, W, kind):
+    from oflk_synth import synth_pair, synth_pair_smooth
+
+    if kind == "synth":
+        return synth_pair(H, W, int(rng.integers(0, 1000)))
+    if kind == "smooth":
+        return synth_pair_smooth(H, W, int(rng.integers(0, 1000)))
+    a = rng.integers(0, 256, (H, W)).astype(np.float32)
+    b = np.roll(a, (1, 2), axis=(0, 1)) + rng.integers(-6, 7, (H, W)).astype(np.float32)
+    return a, np.clip(b, 0, 255).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(240, 320), (241, 323), (97, 131), (64, 48), (33, 250), (480, 644), (270, 480), (23, 21)])
+@pytest.mark.parametrize("kind", ["synth", "noise", "smooth"])
+def test_tolerant_kernels_equal_their_cpu_model(shape, kind):
+    """flows, residual log and iteration counts of a tolerant plan == the CPU model's, value for value: even and odd widths
+    (the 8-byte and the element-wise instantiations), strips with a ragged last one, segments, levels smaller than a strip"""
+    import _oflk
+
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    p, c = _pair(rng, H, W, kind)
+    for (L, K) in ((3, 3), (2, 2), (1, 2), (4, 1)):
+        plan = _oflk.Plan(0, 1, H, W, L, 5, K)
+        plan.set_arithmetic(2)
+        u, v, log, runs = _run(plan, p[None], c[None])
+        mu, mv, mlog, mruns = _model(p, c, L, K)
+        assert list(runs[0]) == list(mruns), (shape, kind, L, K, runs, mruns)
+        bad = np.argwhere(~((u[0] == mu) & (v[0] == mv)))
+        assert bad.size == 0, (shape, kind, L, K, len(bad), bad[:5])
+        for l in range(L):
+            np.testing.assert_allclose(log[0, l, :runs[0, l]], mlog[l, :runs[0, l]], rtol=2e-6, atol=1e-12)
+        plan.close()
+
+
+def test_tolerant_batch_u8_and_switching_back(golden_dir):
+    """a batch of the 13 patterns: float32 and uint8 frames give the model's flows; back in exact mode the plan gives the
+    reference's digests again (the switch leaves nothing behind)"""
+    import hashlib
+
+    import _oflk
+
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    ref = json.loads((golden_dir / "reference_13patterns.json").read_text())["patterns"]
+    names = [k[len("frame_1__"):] for k in z.files if k.startswith("frame_1__")]
+    p8 = np.stack([z["frame_0"]] * len(names))
+    c8 = np.stack([z[f"frame_1__{n}"] for n in names])
+    B, H, W = p8.shape
+    plan = _oflk.Plan(0, B, H, W, 3, 5, 3)
+    plan.set_arithmetic(2)
+    uf, vf, _, rf = _run(plan, p8.astype(np.float32), c8.astype(np.float32))
+    ub, vb, _, rb = _run(plan, p8, c8, u8=True)
+    assert np.array_equal(uf, ub) and np.array_equal(vf, vb) and np.array_equal(rf, rb)
+    for i, n in enumerate(names):
+        mu, mv, _, mruns = _model(p8[i], c8[i], 3, 3)
+        assert np.array_equal(uf[i], mu) and np.array_equal(vf[i], mv) and list(rf[i]) == list(mruns), n
+    plan.set_arithmetic(0)
+    ue, ve, _, _ = _run(plan, p8.astype(np.float32), c8.astype(np.float32))
+    dig = lambda a: hashlib.sha256((np.ascontiguousarray(a, np.float32) + np.float32(0.0)).tobytes()).hexdigest()  # noqa: E731
+    for i, n in enumerate(names):
+        assert dig(ue[i]) == ref[n]["pyramidal"]["u_sha256"] and dig(ve[i]) == ref[n]["pyramidal"]["v_sha256"], n
+    plan.close()
+
+
+def test_tolerant_mode_within_tolerance_of_the_reference(golden_dir):
+    """mean EPE <= 1e-4 per field against the REFERENCE's own dense flows: the 13 patterns and the 1080p bench pair"""
+    import _oflk
+    from oflk_synth import synth_pair
+
+    dense = np.load(golden_dir / "dense_reference_flows.npz")
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    names = [k[len("frame_1__"):] for k in z.files if k.startswith("frame_1__")]
+    p = np.stack([z["frame_0"].astype(np.float32)] * len(names))
+    c = np.stack([z[f"frame_1__{n}"].astype(np.float32) for n in names])
+    plan = _oflk.Plan(0, len(names), 240, 320, 3, 5, 3)
+    plan.set_arithmetic(2)
+    u, v, _, runs = _run(plan, p, c)
+    plan.close()
+    report = {}
+    for i, n in enumerate(names):
+        ru, rv = dense[f"{n}__u"], dense[f"{n}__v"]
+        report[n] = _epe(u[i], v[i], ru, rv)
+        assert list(runs[i]) == list(dense[f"{n}__iters"]), n
+        assert report[n] <= TOL, (n, report[n])
+    pp, cc = synth_pair(1080, 1920, 0)
+    plan = _oflk.Plan(0, 1, 1080, 1920, 3, 5, 3)
+    plan.set_arithmetic(2)
+    u, v, _, runs = _run(plan, pp[None], cc[None])
+    plan.close()
+    report["bench_1080p_pair0"] = _epe(u[0], v[0], dense["bench_1080p_pair0__u"].astype(np.float32),
+                                       dense["bench_1080p_pair0__v"].astype(np.float32))
+    assert list(runs[0]) == list(dense["bench_1080p_pair0__iters"])
+    assert report["bench_1080p_pair0"] <= TOL, report
+    out = Path(__file__).resolve().parents[1] / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    (out / "tolerant_epe.json").write_text(json.dumps({"mean_epe_vs_reference": report, "max": max(report.values()), "bar": TOL}, indent=1))

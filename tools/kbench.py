@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--identical", action="store_true", help="curr = prev (exercises early exit)")
     ap.add_argument("--graph", action="store_true", help="also time one pass captured into a HIP graph")
+    ap.add_argument("--arith", type=int, default=0, help="oflk_plan_set_arithmetic mode of the pyramidal plan (0 exact, 1 contracted, 2 tolerant)")
     args = ap.parse_args()
     import torch
 
@@ -37,6 +38,8 @@ def main():
         ("pyramidal", _oflk.Plan(0, B, H, W, 3, args.window, 3), "pyramidal"),
     ):
         call = getattr(plan, fn)
+        if name == "pyramidal" and args.arith:
+            plan.set_arithmetic(args.arith)
         for _ in range(2):
             call(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
         torch.cuda.synchronize()
