@@ -53,14 +53,27 @@ constexpr int kLksOutW = 120;   // output columns per wave
 #define OFLK_LKS_PFROWS 0     // the prefetch of `curr` runs this many rows ahead of the coalesced loads
 #endif
 #ifndef OFLK_LKS_WAVES
-#define OFLK_LKS_WAVES 4      // waves per SIMD the kernel's register count allows (the host sizes segments with it)
+#define OFLK_LKS_WAVES 2      // waves per SIMD the kernel's register count allows (185 - 193 VGPRs; the host sizes segments with it)
 #endif
 
 // Integer-valued frames, MODE_SINGLE: a window whose Sxx or Syy reaches this bound may have rounded a partial sum
 constexpr float kLksExactBound = 32768.0f;
 
+// timing-only ablations (diagnostic builds, wrong results): 1 no gathers (warp from the coalesced prefetch), 2 no flow
+// re-read, 4 no stores, 8 no solve, 16 no horizontal sums, 32 no lerp arithmetic
+#if defined(OFLK_LKS_ABL) && !defined(OFLK_DIAG)
+#error "OFLK_LKS_ABL is a diagnostic build: add -DOFLK_DIAG"
+#endif
+#ifndef OFLK_LKS_ABL
+#define OFLK_LKS_ABL 0
+#endif
+#ifdef OFLK_LKS_FORCE_WAVES
+#define OFLK_LKS_ATTR __attribute__((amdgpu_waves_per_eu(OFLK_LKS_FORCE_WAVES)))
+#else
+#define OFLK_LKS_ATTR
+#endif
 template <int MODE, bool VEC, int WARPV, class PIX = float>
-__global__ __launch_bounds__(256) void k_lks(LkArgs a)
+__global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
 {
     static_assert(MODE == MODE_SINGLE || MODE == MODE_ITER, "gradient planes take the tile kernel");
     constexpr int HW = 2, R = HW + 1, HL = 2, OUTW = kLksOutW, WPB = 4;
@@ -206,8 +219,10 @@ __global__ __launch_bounds__(256) void k_lks(LkArgs a)
             // int64 + float32 -> float64, as the reference (lucas_kanade_pyramidal.py:88-95)
             gt[0] = lean_frac_at(lg, yd + (double)f.y, gxd0 + (double)f.x);
             gt[1] = lean_frac_at(lg, yd + (double)f.w, gxd1 + (double)f.z);
-            lean_load<false, PIX>(lg, curr, gt[0], g0[0], g1[0]);
-            lean_load<false, PIX>(lg, curr, gt[1], g0[1], g1[1]);
+            if constexpr (!(OFLK_LKS_ABL & 1)) {
+                lean_load<false, PIX>(lg, curr, gt[0], g0[0], g1[0]);
+                lean_load<false, PIX>(lg, curr, gt[1], g0[1], g1[1]);
+            }
         }
     };
 
@@ -226,7 +241,11 @@ __global__ __launch_bounds__(256) void k_lks(LkArgs a)
             if constexpr (MODE == MODE_ITER) touch = fmaxf(touch, Cr[j]);
             float2 q;
             if constexpr (MODE == MODE_ITER) {
-                if constexpr (WARPV == WARP_LERP64) {
+                if constexpr ((OFLK_LKS_ABL & 1) != 0) {
+                    q.x = Cr[j] + (float)gt[0].rx; q.y = Cr[j] + (float)gt[1].ry;
+                } else if constexpr ((OFLK_LKS_ABL & 32) != 0) {
+                    q.x = g0[0].a + g1[0].b + (float)gt[0].rx; q.y = g0[1].a + g1[1].b + (float)gt[1].ry;
+                } else if constexpr (WARPV == WARP_LERP64) {
                     q.x = lerp64_finish(gt[0], g0[0], g1[0]);
                     q.y = lerp64_finish(gt[1], g0[1], g1[1]);
                 } else {
@@ -246,7 +265,8 @@ __global__ __launch_bounds__(256) void k_lks(LkArgs a)
             // loads three rows ahead -- and every wait leaves the younger ones in flight.
             float4 pf = pf_next;   // (lane_out lanes of a VEC launch lie inside the frame: no fix-up needed)
             if constexpr (MODE == MODE_ITER) {
-                if (o + 1 >= ys) pf_next = load_flow2(fin, row_e(o + 1));
+                if constexpr (!(OFLK_LKS_ABL & 2))
+                    if (o + 1 >= ys) pf_next = load_flow2(fin, row_e(o + 1));
                 issue_gathers((j + 1) % 3, r + 1);            // used by the next row, after this row's arithmetic
             }
             issue_loads(j, r + LD);
@@ -308,13 +328,15 @@ __global__ __launch_bounds__(256) void k_lks(LkArgs a)
                 S[pl][0] = X + wshift<SHL>(lo);                // ... + V[c+2]
                 const float Y = wshift<SHR>(hi) + pp;          // V[c-2] + (V[c-1] + V[c])      (c = the odd column)
                 S[pl][1] = Y + wshift<SHL>(pp);                // ... + (V[c+1] + V[c+2])
+                if constexpr ((OFLK_LKS_ABL & 16) != 0) { S[pl][0] = lo; S[pl][1] = hi; }
             }
             const bool oky = o >= HW && o < H - HW;            // borders stay 0 (lucas_kanade_core.py:101-108)
             float du[2], dv[2];
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 float uu, vv;
-                lk_solve(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], uu, vv);
+                if constexpr ((OFLK_LKS_ABL & 8) != 0) { uu = S[0][c] + S[1][c] + S[2][c]; vv = S[3][c] + S[4][c]; }
+                else lk_solve(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], uu, vv);
                 const bool interior = oky && (c ? in1 : in0);
                 du[c] = interior ? uu : 0.0f;
                 dv[c] = interior ? vv : 0.0f;
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(256) void k_lks(LkArgs a)
                     }
                 }
             }
-            if (lane_out && o_live) {
+            if (lane_out && o_live && (!(OFLK_LKS_ABL & 4) || du[0] == 1.25e37f)) {
                 const unsigned orow = (unsigned)(o * W);
                 float2 ru = make_float2(du[0], du[1]), rv = make_float2(dv[0], dv[1]);
                 if constexpr (MODE == MODE_ITER) {

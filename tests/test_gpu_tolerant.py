@@ -74,8 +74,8 @@ def test_tolerant_kernels_equal_their_cpu_model(shape, kind):
         assert list(runs[0]) == list(mruns), (shape, kind, L, K, runs, mruns)
         bad = np.argwhere(~((u[0] == mu) & (v[0] == mv)))
         assert bad.size == 0, (shape, kind, L, K, len(bad), bad[:5])
-        for l in range(L):
-            np.testing.assert_allclose(log[0, l, :runs[0, l]], mlog[l, :runs[0, l]], rtol=2e-6, atol=1e-12)
+        for l in range(L):   # the device sums |d| in fixed point, NumPy in fp32 pairwise: an outlier among few pixels costs NumPy 1e-5
+            np.testing.assert_allclose(log[0, l, :runs[0, l]], mlog[l, :runs[0, l]], rtol=2e-5, atol=1e-12)
         plan.close()
 
 
