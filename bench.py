@@ -399,7 +399,8 @@ def main() -> None:
         if world == 1 and not args.no_live_traffic and args.levels == 3 and args.window == 5 and args.iters == 3:
             live = live_traffic(B, (H, W))
         ib = profile_file("issue_bounds", B, (H, W), any_pairs=True)
-        roofline = {"bound": "hbm", "kernel": "k_lkw<2,ITER> (fused LK iteration, finest level)",
+        roofline = {"bound": "hbm", "binding_pipe": "valu", "timed_with_profiling": 2,
+                    "kernel": "k_lkw<2,ITER> (fused LK iteration, finest level)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": live["hbm_bytes_per_launch"] if live else (tr["hbm_bytes_per_launch"] if tr else None),
@@ -486,6 +487,75 @@ def main() -> None:
                       "mean_epe_vs_exact": float(d2.sqrt().mean().item()),
                       "note": "oflk_plan_set_arithmetic(OFLK_ARITH_CONTRACTED): opt-in, not the metric's value"}
         del u_ex, v_ex, d2
+        step()   # leave the exact result in u, v
+        torch.cuda.synchronize()
+
+    # ---- the opt-in within-tolerance arithmetic (oflk_plan_set_arithmetic(OFLK_ARITH_TOLERANT); include/oflk.h): never `value`.
+    # Timed like the exact mode (HIP events around the dominant kernel only), then graded against the REFERENCE's own dense
+    # flows (tests/golden/dense_reference_flows.npz, made by importing it): the 13 verification patterns and pair 0 of this
+    # workload; the bar is the north star's mean endpoint error <= 1e-4 px per field ----
+    tolerant = None
+    if rank == 0 and world == 1 and L > 1 and args.window in (4, 5):
+        plan.set_arithmetic(2)
+        for _ in range(2):
+            step()
+        plan.set_profiling(2)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        nrep = max(3, min(args.steps, 10))
+        for _ in range(nrep):
+            step()
+        torch.cuda.synchronize()
+        c1 = time.perf_counter()
+        kt = plan.kernel_times().get("lk_iter_finest", {"total_ms": 0.0, "launches": 0})
+        plan.set_profiling(0)
+        tol_ms = 1e3 * (c1 - c0) / nrep
+        tolerant = {"value": round(nrep * B * H * W / (c1 - c0) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(tol_ms, 4),
+                    "timed_with_profiling": 2,
+                    "note": "oflk_plan_set_arithmetic(OFLK_ARITH_TOLERANT): opt-in, not the metric's value. Pyramid with fused multiply-adds; the "
+                            "iterations of the two finest levels in the streaming kernel k_lks (fused-lerp fp64 warp, window sums vertical-then-"
+                            "horizontal instead of NumPy's order); coarser levels, solve and flow upsampling exact"}
+        if kt["launches"]:
+            t_ms = kt["total_ms"] / kt["launches"]
+            bpl = model["finest_iteration_launch"] * B
+            tolerant["roofline"] = {"bound": "hbm", "binding_pipe": "hbm", "kernel": "k_lks<ITER> (streaming LK iteration, finest level)",
+                                    "achieved": round(bpl / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(bpl / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": round(t_ms * 1e3, 2),
+                                    "algorithmic_bytes_per_launch": bpl, "traffic": None}
+        try:
+            dense = np.load(ROOT / "tests" / "golden" / "dense_reference_flows.npz")
+            z = np.load(ROOT / "tests" / "golden" / "patterns_320x240.npz")
+            names = [k[len("frame_1__"):] for k in z.files if k.startswith("frame_1__")]
+
+            def mean_epe(uu, vv, ru, rv):
+                return float(np.mean(np.sqrt((uu.astype(np.float64) - ru) ** 2 + (vv.astype(np.float64) - rv) ** 2)))
+
+            epes = {}
+            if (H, W, L, K) == (1080, 1920, 3, 3) and lay.pair_begin == 0:
+                epes["workload_pair0"] = mean_epe(u[0].cpu().numpy(), v[0].cpu().numpy(), dense["bench_1080p_pair0__u"], dense["bench_1080p_pair0__v"])
+            pp = torch.from_numpy(np.stack([z["frame_0"].astype(np.float32)] * len(names))).to(dev)
+            cc = torch.from_numpy(np.stack([z[f"frame_1__{n}"].astype(np.float32) for n in names])).to(dev)
+            pu, pv = torch.empty_like(pp), torch.empty_like(pp)
+            plan13 = _oflk.Plan(local_rank, len(names), 240, 320, 3, 5, 3)
+            plan13.set_arithmetic(2)
+            plan13.pyramidal(pp.data_ptr(), cc.data_ptr(), pu.data_ptr(), pv.data_ptr(), stream)
+            torch.cuda.synchronize()
+            plan13.close()
+            hu, hv = pu.cpu().numpy(), pv.cpu().numpy()
+            for i, n in enumerate(names):
+                epes[n] = mean_epe(hu[i], hv[i], dense[f"{n}__u"], dense[f"{n}__v"])
+            worst = max(epes, key=epes.get)
+            tolerant["max_mean_epe_vs_reference"] = epes[worst]
+            tolerant["worst_field"] = worst
+            tolerant["fields"] = len(epes)
+            tolerant["fields_within_1e-4"] = int(sum(e <= 1e-4 for e in epes.values()))
+            if "workload_pair0" in epes:
+                tolerant["mean_epe_workload_pair0"] = epes["workload_pair0"]
+            tolerant["reference"] = "tests/golden/dense_reference_flows.npz: dense flows of the reference itself (13 verification patterns + pair 0 of this workload)"
+        except Exception as e:   # the fixture is part of the repository; a run without it still reports the timing
+            tolerant["max_mean_epe_vs_reference"] = None
+            tolerant["epe_error"] = repr(e)
+        plan.set_arithmetic(0)
         step()   # leave the exact result in u, v
         torch.cuda.synchronize()
 
@@ -592,6 +662,7 @@ def main() -> None:
             "kernels": kernels,
             "job_stats": job_stats,
             "contracted_arithmetic": contracted,
+            "tolerance_mode": tolerant,
             "one_pair_per_call": one_pair,
             "cpu_baseline": cpu,
             "epe_vs_reference": parity,

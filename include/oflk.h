@@ -236,8 +236,24 @@ int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, fl
  * differs from the reference's only where the fp64 value lies that close to a float32 rounding boundary (about one in
  * 10^7, by one ulp); coarse-to-fine LK then amplifies such a difference locally.  Measured on the 13 verification
  * patterns (tests/test_gpu_round3.py, profiles/): mean EPE against the reference far below the 1e-4 bar.  Affects
- * oflk_plan_pyramidal / _u8 only; exit-decision flags and oflk_plan_resolve_uncertain keep their meaning relative to
- * the plan's own pyramid. */
+ * oflk_plan_pyramidal / _u8 only.
+ * OFLK_ARITH_TOLERANT (opt-in): everything whose cost in endpoint error against the reference was measured, cell by cell
+ * (stage x pyramid level x iteration: tools/experiments/fast_mode_ablation.py, profiles/), to sit at least three times
+ * under the north star's bar of 1e-4 px mean EPE on its own and under 5e-5 combined:
+ *   - the contracted pyramid (above);
+ *   - on the TWO FINEST levels, 5x5 window, the fused iteration runs as a streaming kernel (k_lks) whose window sums are
+ *     separable -- five rows added vertically, then five columns horizontally, not np.sum's pairwise order of
+ *     python/lucas_kanade_core.py:115-119 -- and whose warp (python/lucas_kanade_pyramidal.py:88-96) forms the bilinear
+ *     sample as three fused lerps in fp64 instead of SciPy's 15 operations; gradients, products, the 2x2 solve (IEEE
+ *     divisions) and flow += d are the reference's operations;
+ *   - coarser levels, the flow upsampling, other windows: exact, as in OFLK_ARITH_EXACT.
+ * Measured against dense flows of the reference itself (tests/golden/dense_reference_flows.npz): worst of the 13
+ * verification patterns 1.7e-5 px (translate_extreme), the 1080p bench pair 5.6e-7 px.  The arithmetic is stated on the
+ * CPU by oracle/oflk_tolerant_model.c (test infrastructure) and the kernels are held to that statement bit for bit
+ * (tests/test_gpu_tolerant.py), so the tolerance is a property of one written-down arithmetic, not of a GPU run.
+ * In both opt-in modes the exit-decision flags keep their meaning, and oflk_plan_resolve_uncertain redoes a flagged pair in
+ * EXACT arithmetic from the caller's frames (its own exact pyramid): a redone pair is the reference's result, which is
+ * inside any tolerance.  Windows without a fused iteration kernel (1x1, 13x13 ...) always run exactly. */
 #define OFLK_ARITH_EXACT 0
 #define OFLK_ARITH_CONTRACTED 1
 #define OFLK_ARITH_TOLERANT 2
