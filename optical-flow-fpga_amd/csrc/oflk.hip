@@ -162,10 +162,10 @@ int window_hw(int window_size, int *hw)
 
 // ---- kernel classes for the per-kernel event timing --------------------------
 enum KClass { KC_LK_SINGLE = 0, KC_LK_ITER, KC_LK_ITER_FINEST, KC_BLUR, KC_RESAMPLE,
-              KC_UPSAMPLE, KC_EXPORT, KC_INIT, KC_PYR_FUSED, KC_COUNT };
+              KC_UPSAMPLE, KC_EXPORT, KC_INIT, KC_PYR_FUSED, KC_LK_REDO, KC_COUNT };
 const char *kClassNames[KC_COUNT] = {"lk_single", "lk_iter", "lk_iter_finest", "blur",
                                      "pyr_resample", "flow_upsample", "export_fixup", "call_init",
-                                     "pyr_down_fused"};
+                                     "pyr_down_fused", "lk_single_redo"};
 
 }  // namespace
 
@@ -194,6 +194,9 @@ struct oflk_plan {
     } exact;
     GaussW gauss;
     int arith = OFLK_ARITH_EXACT;   // oflk_plan_set_arithmetic
+    int kernels = OFLK_KERNELS_AUTO;   // oflk_plan_set_kernels
+    // single-scale 5x5 on integer-valued frames: the streaming kernel's list of doubtful tiles (LkArgs::redo)
+    unsigned *redo = nullptr;
 #ifdef OFLK_STAMPS
     unsigned *stamps = nullptr;      // diagnostic build: per-wave section cycle sums of the last finest-level launch
     size_t stamps_blocks = 0;
@@ -318,7 +321,11 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     // seg_row holds tile rows as unsigned short
     if (MODE == MODE_GRADS || hw > 2 || cap_env <= 1 || per_slot < 10 || tiles_y > 65535) cap = 1;   // kLkChain
     unsigned nblocks;
-    if (cap <= 1) {
+    if (MODE == MODE_SINGLE && a.redo_pass) {
+        // redo pass of the streaming kernel: resident blocks that walk the device-side list of flagged tiles
+        a.nseg = 0;
+        nblocks = (unsigned)std::min<long>((long)B * tiles_x * tiles_y, 1024);
+    } else if (cap <= 1) {
         a.nseg = 0;
         nblocks = (unsigned)(tiles_x * tiles_y * B);
     } else {
@@ -391,7 +398,7 @@ int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int 
     a.B = B;
     Prof pr(plan, s, cls);
     const long strips = ((long)a.W + kLksOutW - 1) / kLksOutW * B;
-    const long slots = 256 * 4 * OFLK_LKS_WAVES;   // wave slots of the chip at the kernel's occupancy
+    const long slots = 256 * 4 * (MODE == MODE_SINGLE ? 4 : OFLK_LKS_WAVES);   // wave slots of the chip at the kernel's occupancy (SINGLE: ~100 VGPRs)
     long segs = ((long)a.H + 63) / 64;
     const double rounds = (double)(strips * segs) / (double)slots;
     if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
@@ -613,6 +620,7 @@ void plan_free(oflk_plan *p)
     if (p->tmpA) (void)hipFree(p->tmpA);
     if (p->tmpB) (void)hipFree(p->tmpB);
     if (p->state) (void)hipFree(p->state);
+    if (p->redo) (void)hipFree(p->redo);
     for (auto &q : p->u8_stage)
         if (q) (void)hipFree(q);
     for (int l = 0; l < OFLK_MAX_LEVELS; l++)
@@ -703,6 +711,12 @@ OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, 
         if (!rc && (iters > 0 || levels > 1)) rc = dmalloc(&p->flow[l], (size_t)2 * 2 * B * n, &p->ws_bytes);   // two interleaved slots
     }
     if (!rc) rc = dmalloc(&p->state, p->state_words() / 2, &p->ws_bytes);
+    if (!rc && p->hw == 2) {
+        // redo list of the single-scale streaming kernel (LkArgs::redo): all zero between calls
+        const size_t n = 2 + 2 * (size_t)B * ((W + k5TX - 1) / k5TX) * ((H + k5TY - 1) / k5TY);
+        rc = dmalloc(&p->redo, n, &p->ws_bytes);
+        if (!rc && hipMemset(p->redo, 0, std::max<size_t>(n * sizeof(unsigned), 256)) != hipSuccess) rc = fail(OFLK_ERR_HIP, "hipMemset of the redo list failed");
+    }
     if (rc) {
         std::string keep = t_err;
         plan_free(p);
@@ -732,6 +746,16 @@ int plan_single_scale(oflk_plan *p, const void *d_prev, const void *d_curr, bool
     a.curr = static_cast<const float *>(d_curr);
     a.ou = d_u; a.ov = d_v;
     a.H = p->H; a.W = p->W;
+    if (p->hw == 2 && p->H > 4 && p->W > 4 && p->kernels == OFLK_KERNELS_AUTO) {
+        // 5x5 window: the streaming kernel, whose order-free sums are NumPy's wherever the frames are integers in [0, 255]
+        // and a window's Sxx, Syy stay below 2^16 (proof at kLksExactBound); it flags the tiles where that is in doubt and
+        // the tile kernel redoes exactly those in NumPy's order.  Results are the reference's either way.
+        a.redo = p->redo;   // allocated and zeroed with the plan
+        int rc = launch_lks<MODE_SINGLE>(p, s, KC_LK_SINGLE, a, p->B, u8, WARP_SCIPY);
+        if (rc) return rc;
+        a.redo_pass = 1;
+        return launch_lk<MODE_SINGLE>(p, s, KC_LK_REDO, p->hw, a, p->B, u8);
+    }
     return launch_lk<MODE_SINGLE>(p, s, KC_LK_SINGLE, p->hw, a, p->B, u8);
 }
 int plan_pyramidal(oflk_plan *p, const void *d_prev, const void *d_curr, bool u8, float *d_u, float *d_v, hipStream_t s);
@@ -1214,6 +1238,15 @@ OFLK_API int oflk_plan_set_arithmetic(oflk_plan *p, int mode)
     if (mode != OFLK_ARITH_EXACT && mode != OFLK_ARITH_CONTRACTED && mode != OFLK_ARITH_TOLERANT)
         return fail(OFLK_ERR_INVALID, "arithmetic mode must be OFLK_ARITH_EXACT (0), OFLK_ARITH_CONTRACTED (1) or OFLK_ARITH_TOLERANT (2), got %d", mode);
     p->arith = mode;
+    return OFLK_OK;
+}
+
+OFLK_API int oflk_plan_set_kernels(oflk_plan *p, int choice)
+{
+    if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
+    if (choice != OFLK_KERNELS_AUTO && choice != OFLK_KERNELS_TILE)
+        return fail(OFLK_ERR_INVALID, "kernel choice must be OFLK_KERNELS_AUTO (0) or OFLK_KERNELS_TILE (1), got %d", choice);
+    p->kernels = choice;
     return OFLK_OK;
 }
 

@@ -323,7 +323,40 @@ __device__ __forceinline__ double linspace_at(const Linspace &l, int i)
     return (double)i * l.step;  // step == 0 (S == 1) also yields 0, as NumPy does
 }
 
-// 2x2 Cramer solve, every op individually rounded (lucas_kanade_core.py:122-133)
+// Two correctly rounded float32 quotients nu / d, nv / d that share one reciprocal: v_rcp_f32 refined once, then per
+// quotient the product, two remainder corrections and the final fused correction -- the compiler's own IEEE expansion
+// (rcp, fma x2, mul, fma x4) minus its range scaling (v_div_scale / v_div_fmas / v_div_fixup), with the reciprocal's three
+// instructions paid once: 13 instructions for two quotients instead of 22.  Equal to nu / d, nv / d bit for bit PROVIDED
+// nothing leaves the normal range: 2^-64 < |d| < 2^64 and each numerator is 0 or 2^-40 <= |n| < 2^60 (then |q| and every
+// remainder n - d q stay normal, so each fma's exact argument is representable as Markstein's argument needs; a zero
+// numerator gives a zero of either sign, equal as a value).  Callers establish the range (k_lks on verified 8-bit frames).
+__device__ __forceinline__ void div2_shared_rcp(float nu, float nv, float d, float &qu, float &qv)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r = __builtin_fmaf(e0, r0, r0);
+    float q = nu * r;
+    float e = __builtin_fmaf(-d, q, nu);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, nu);
+    qu = __builtin_fmaf(e, r, q);
+    q = nv * r;
+    e = __builtin_fmaf(-d, q, nv);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, nv);
+    qv = __builtin_fmaf(e, r, q);
+}
+
+#ifndef OFLK_PROBE_FASTDIV
+#define OFLK_PROBE_FASTDIV 0   // diagnostic builds only: the shared-reciprocal quotients everywhere, unguarded (timing probe)
+#endif
+#if OFLK_PROBE_FASTDIV && !defined(OFLK_DIAG)
+#error "OFLK_PROBE_FASTDIV is a diagnostic build: add -DOFLK_DIAG"
+#endif
+
+// 2x2 Cramer solve, every op individually rounded (lucas_kanade_core.py:122-133).  SAFE_RANGE: the caller guarantees
+// div2_shared_rcp's range conditions, and the two divisions share their reciprocal (same values).
+template <bool SAFE_RANGE = false>
 __device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float Sxt, float Syt,
                                          float &u, float &v)
 {
@@ -337,8 +370,12 @@ __device__ __forceinline__ void lk_solve(float Sxx, float Syy, float Sxy, float 
         float n0 = Syy * b0, n1 = Sxy * b1;
         float n2 = Sxx * b1, n3 = Sxy * b0;
         float nu = n0 - n1, nv = n2 - n3;
-        u = nu / det;
-        v = nv / det;
+        if constexpr (SAFE_RANGE || OFLK_PROBE_FASTDIV) {
+            div2_shared_rcp(nu, nv, det, u, v);
+        } else {
+            u = nu / det;
+            v = nv / det;
+        }
     }
 }
 
@@ -383,10 +420,14 @@ struct LkArgs {
     unsigned short seg_row[kMaxSegs + 1];
     // streaming kernel k_lks (oflk_stream.hpp): rows per segment, segments per strip
     int Hs, segs;
-    // SINGLE on integer-valued frames: one byte per 64 x 24 tile, [B][tiles_y][tiles_x].  k_lks sets the flag of a tile
-    // in which its order-free window sums may differ from NumPy's; k_lkw launched with the same pointer redoes exactly
-    // the flagged tiles (and clears their flags).  nullptr: no flags / every tile.
-    unsigned char *redo;
+    // SINGLE 5x5 on integer-valued frames: redo list shared by k_lks and k_lkw, 32-bit words
+    //   [0] entries in the list   [1] ticket of the redo pass   [2 .. 2+T) one flag per 64 x 24 tile, T = B * tiles_y * tiles_x
+    //   [2+T .. 2+2T) the list: tile indices (b * tiles_y + tile_y) * tiles_x + tile_x
+    // k_lks appends the tiles in which its order-free window sums may differ from NumPy's (flag = dedup); k_lkw launched
+    // with redo_pass = 1 walks the list -- block i takes entries i, i + gridDim.x, ... -- clears the flags, and its last
+    // block to finish resets [0] and [1]: the buffer is all zero between calls.  nullptr: no list.
+    unsigned *redo;
+    int redo_pass;
 #ifdef OFLK_STAMPS
     unsigned *stamps;   // diagnostic build only: [block][wave][16] cycle sums per code section
 #endif
@@ -1014,19 +1055,23 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     // windows above 5x5 run one tile per block: their sum stage needs the registers the loop
     // and the carried rows would take (7x7: 153 -> 172 VGPRs, 3 -> 2 waves per SIMD)
     constexpr bool CHAIN = kLkChain<HW, MODE>;
+    // the redo pass of k_lks (SINGLE, 5x5): the block walks its share of the list of flagged tiles, one tile per trip
+    constexpr bool CAN_REDO = MODE == MODE_SINGLE && HW == 2;
+    const bool redo = CAN_REDO && a.redo_pass != 0;   // uniform
     int b, tile_x, tile_y_first, ntile;
-    if (!CHAIN || a.nseg == 0) {
+    if (redo) {
+        const unsigned count = a.redo[0];
+        ntile = blockIdx.x < count ? (int)((count - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+        b = 0;
+        tile_x = 0;
+        tile_y_first = 0;
+    } else if (!CHAIN || a.nseg == 0) {
         const int tile = xcd_tile_index(blockIdx.x, tiles_x * tiles_y * a.B);
         b = tile / (tiles_x * tiles_y);
         const int t = tile - b * (tiles_x * tiles_y);
         tile_y_first = t / tiles_x;
         tile_x = t - tile_y_first * tiles_x;
         ntile = 1;
-        if (MODE == MODE_SINGLE && a.redo != nullptr) {   // uniform: redo pass after k_lks, flagged tiles only
-            if (!a.redo[tile]) return;
-            __syncthreads();                               // every thread has read the flag
-            if (threadIdx.x == 0) a.redo[tile] = 0;
-        }
     } else {
         // XCD x (block ids x, x+8, ...) owns the column strips [x*S/8, (x+1)*S/8) and runs
         // their segments longest first (seg_row is built that way), so the blocks still in
@@ -1051,9 +1096,9 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     }
     const size_t plane = (size_t)H * (size_t)W;
     // frame planes of pair b; PIX-sized elements (a.prev / a.curr are typed float for the common case)
-    const PIX *__restrict__ prev = reinterpret_cast<const PIX *>(a.prev) + (size_t)b * plane;
+    const PIX *__restrict__ prev = reinterpret_cast<const PIX *>(a.prev) + (size_t)b * plane;   // (re-pointed per trip by a redo pass)
     const PIX *__restrict__ curr = reinterpret_cast<const PIX *>(a.curr) + (size_t)b * plane;
-    const int x0 = tile_x * k5TX;
+    int x0 = tile_x * k5TX;
     float carry_a[NC], carry_i[NC];
     double blk_u = 0.0, blk_v = 0.0;   // thread 0: |d| sums of the block's tiles
 
@@ -1122,9 +1167,23 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         // three stages is hoisted out of the loop and held in registers (occupancy 4 -> 2)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int tile_y = tile_y_first + it;
+        if constexpr (CAN_REDO) {
+            if (redo) {   // uniform: this trip's tile comes from the list
+                const unsigned T = (unsigned)(tiles_x * tiles_y * a.B);
+                const unsigned tile = a.redo[2u + T + blockIdx.x + (unsigned)it * gridDim.x];
+                b = (int)(tile / (unsigned)(tiles_x * tiles_y));
+                const int t = (int)tile - b * (tiles_x * tiles_y);
+                tile_y_first = t / tiles_x;
+                tile_x = t - tile_y_first * tiles_x;
+                x0 = tile_x * k5TX;
+                prev = reinterpret_cast<const PIX *>(a.prev) + (size_t)b * plane;
+                curr = reinterpret_cast<const PIX *>(a.curr) + (size_t)b * plane;
+                if (threadIdx.x == 0) a.redo[2u + tile] = 0u;
+            }
+        }
+        const int tile_y = redo ? tile_y_first : tile_y_first + it;
         const int y0 = tile_y * k5TY;
-        const int rstart = (!CHAIN || it == 0) ? 0 : 2 * R;  // first staging row to compute
+        const int rstart = (!CHAIN || it == 0 || redo) ? 0 : 2 * R;  // first staging row to compute
 #ifdef OFLK_STAMPS
         st_tile = it;
 #endif
@@ -1146,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
             }
         } else {
             // ---- stage 1: second frame (warped if ITER), frame average, It -------
-            if (CHAIN && it > 0) {
+            if (CHAIN && it > 0 && !redo) {
                 // rows 0 .. 2R-1 are the previous tile's rows TY .. AH-1
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
@@ -1341,7 +1400,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
                     git[RPW2 + h] = s_it[(r + 1) * AS + (c + GC)];
                 }
             }
-            if (CHAIN && it + 1 < ntile) {
+            if (CHAIN && it + 1 < ntile && !redo) {
                 // staging rows TY .. AH-1 are the next tile's rows 0 .. 2R-1
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
@@ -1553,6 +1612,16 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     bt[2] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
     if (MODE == MODE_ITER && threadIdx.x == 0) lk_report(a, b, blk_u, blk_v);
+    if constexpr (CAN_REDO) {
+        // every block read the count when it started; the last one to finish leaves the list empty for the next call
+        if (redo && threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&a.redo[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                a.redo[0] = 0u;
+                a.redo[1] = 0u;
+            }
+        }
+    }
 #ifdef OFLK_STAMPS
     __syncthreads();
     if (a.stamps) {

@@ -24,8 +24,9 @@
 //    the 1e-4 bar (tools/experiments/fast_mode_ablation.py: what each cell of the pass costs).
 //  * MODE_SINGLE on integer-valued frames (EXACT): gradients are multiples of 1/16 there, products of 2^-8 (2^-4
 //    with It), so while a window's sums stay below 2^16 every partial sum is exact in any order and the separable
-//    sums ARE NumPy's.  A wave checks Sxx, Syy < 2^15 on every window it solves and flags the 64 x 24 tiles where
-//    that fails; the tile kernel k_lkw then redoes exactly those tiles (k_lkw's `redo` list).
+//    sums ARE NumPy's (proof at kLksExactBound).  A wave checks Sxx, Syy < 2^16 on every window it solves -- and, for
+//    float32 frames, that every pixel it loads is an integer in [0, 255] -- and flags the 64 x 24 tiles where that fails;
+//    the tile kernel k_lkw then redoes exactly those tiles in NumPy's order (k_lkw's `redo` flags).
 #pragma once
 
 namespace oflk {
@@ -52,12 +53,28 @@ constexpr int kLksOutW = 120;   // output columns per wave
 #ifndef OFLK_LKS_PFROWS
 #define OFLK_LKS_PFROWS 0     // the prefetch of `curr` runs this many rows ahead of the coalesced loads
 #endif
+#ifndef OFLK_LKS_LD_SINGLE
+#define OFLK_LKS_LD_SINGLE 3
+#endif
+#ifndef OFLK_LKS_LD_ITER
+#define OFLK_LKS_LD_ITER 3
+#endif
 #ifndef OFLK_LKS_WAVES
 #define OFLK_LKS_WAVES 2      // waves per SIMD the kernel's register count allows (185 - 193 VGPRs; the host sizes segments with it)
 #endif
 
-// Integer-valued frames, MODE_SINGLE: a window whose Sxx or Syy reaches this bound may have rounded a partial sum
-constexpr float kLksExactBound = 32768.0f;
+// MODE_SINGLE on integer-valued frames p, q in [0, 255] (lucas_kanade_core.py:36-43, :110-119): avg = (p + q)/2 is a
+// multiple of 1/2, Ix and Iy (Sobel weights 1/8, 1/4) multiples of 1/16 with |Ix| <= 127.5, It = p - q an integer with
+// |It| <= 255 -- all exact.  The products are exact too (11-bit x 11-bit, 11-bit x 9-bit significands): Ix*Ix, Iy*Iy, Ix*Iy
+// multiples of 2^-8, Ix*It, Iy*It multiples of 2^-4.  A float32 sum of multiples of g is exact while it stays below 2^24 g.
+// With B = Sxx, Syy < 2^16:
+//   every partial sum of the non-negative terms of Sxx (Syy) is <= Sxx (Syy) < 2^16 = 2^24 * 2^-8                  -> exact
+//   every partial sum of Sxy is bounded by sum |Ix Iy| <= (Sxx + Syy) / 2 < 2^16                                    -> exact
+//   every partial sum of Sxt by sum |Ix It| <= sqrt(Sxx * sum It^2) <= sqrt(2^16 * 25 * 255^2) = 326 400 < 2^20 = 2^24 * 2^-4 -> exact
+// so the five sums are the exact real numbers in ANY order of additions, hence equal to np.sum's; the solve that follows
+// is the reference's operation sequence on equal inputs.  A window that fails the bound (or a pixel that is not such an
+// integer) flags its tile for the NumPy-order kernel.
+constexpr float kLksExactBound = 65536.0f;
 
 // timing-only ablations (diagnostic builds, wrong results): 1 no gathers (warp from the coalesced prefetch), 2 no flow
 // re-read, 4 no stores, 8 no solve, 16 no horizontal sums, 32 no lerp arithmetic
@@ -169,7 +186,11 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     const double gxd0 = (double)c0, gxd1 = (double)c1;
 
     // ---- pipeline state ------------------------------------------------------------------------------------
-    constexpr int LD = 3;                 // coalesced loads run LD rows ahead of the arithmetic
+    // coalesced loads run LD rows ahead of the arithmetic (a multiple of 3, the period of the other rings: the row loop is
+    // unrolled LD times so that every ring slot is a compile-time index).  Bytes in flight are what a streaming kernel lives
+    // on: a wave holds LD rows of 16 - 28 bytes per lane
+    constexpr int LD = MODE == MODE_SINGLE ? OFLK_LKS_LD_SINGLE : OFLK_LKS_LD_ITER;
+    static_assert(LD % 3 == 0, "the load ring's period must be a multiple of the other rings' period");
     float2 Pr[LD];                        // prev rows
     float2 Qr[LD];                        // SINGLE: curr rows
     float4 Fr[LD];                        // ITER: flow rows
@@ -190,7 +211,8 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     for (int pl = 0; pl < 5; pl++) P1[pl][0] = P1[pl][1] = 0.0f;
     float su = 0.0f, sv = 0.0f;           // |d| sums of the current three rows
     double dsu = 0.0, dsv = 0.0;          // ... of the segment
-    unsigned inexact = 0u;                // SINGLE: a solved window reached kLksExactBound in one of the last 24 rows
+    unsigned inexact = 0u;                // SINGLE: a window of this lane's neighbourhood may differ from NumPy's (since the last flush)
+    int hold = 0;                         // SINGLE, float32 frames: iterations a non-integral pixel keeps `inexact` set
     float4 pf_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // ITER: the flow of the next output row
 
     const int r0 = ys - R;                // first average row
@@ -230,19 +252,20 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     for (int k = 0; k < LD; k++) issue_loads(k, r0 + k);
     issue_gathers(0, r0);
 
-    for (int i0 = 0; i0 < n_it; i0 += 3) {
-        static_for(std::make_integer_sequence<int, 3>{}, [&](auto jc) {
-            constexpr int j = decltype(jc)::value;            // = i mod 3: ring slots are static
-            const int i = i0 + j;   // (the last trip may run up to two rows past the segment: clamped loads, no stores)
+    for (int i0 = 0; i0 < n_it; i0 += LD) {
+        static_for(std::make_integer_sequence<int, LD>{}, [&](auto jc) {
+            constexpr int jl = decltype(jc)::value;           // = i mod LD: slot of the load rings
+            constexpr int j = jl % 3;                         // = i mod 3: slot of the other rings
+            const int i = i0 + jl;   // (the last trip may run up to LD - 1 rows past the segment: clamped loads, no stores)
             const int r = r0 + i;
             // ---- second frame of row r (warped if ITER), frame average, It --------------------------------
-            float2 p = Pr[j];
+            float2 p = Pr[jl];
             fix_pix2(p);
-            if constexpr (MODE == MODE_ITER) touch = fmaxf(touch, Cr[j]);
+            if constexpr (MODE == MODE_ITER) touch = fmaxf(touch, Cr[jl]);
             float2 q;
             if constexpr (MODE == MODE_ITER) {
                 if constexpr ((OFLK_LKS_ABL & 1) != 0) {
-                    q.x = Cr[j] + (float)gt[0].rx; q.y = Cr[j] + (float)gt[1].ry;
+                    q.x = Cr[jl] + (float)gt[0].rx; q.y = Cr[jl] + (float)gt[1].ry;
                 } else if constexpr ((OFLK_LKS_ABL & 32) != 0) {
                     q.x = g0[0].a + g1[0].b + (float)gt[0].rx; q.y = g0[1].a + g1[1].b + (float)gt[1].ry;
                 } else if constexpr (WARPV == WARP_LERP64) {
@@ -253,8 +276,21 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
                     q.y = lean_finish(gt[1], g0[1], g1[1]);
                 }
             } else {
-                q = Qr[j];
+                q = Qr[jl];
                 fix_pix2(q);
+                if constexpr (sizeof(PIX) == 4) {
+                    // a float32 frame is only promised to be what the verifier makes of 8-bit files (optical_flow_verifier.py:61-65);
+                    // a pixel that is not an integer in [0, 255] voids the exactness argument for the windows it touches: the
+                    // outputs completed by this and the next six iterations, three columns either side
+                    auto integral = [](float t) { return t == __builtin_truncf(t) && fabsf(t - 127.5f) <= 127.5f; };
+                    if (!(integral(p.x) && integral(p.y) && integral(q.x) && integral(q.y))) hold = 7;
+                }
+            }
+            if constexpr (MODE == MODE_SINGLE) {
+                if (hold > 0) {
+                    inexact |= 1u;
+                    hold--;
+                }
             }
             const int o = r - R;                               // the output row this iteration completes
             const bool o_live = o >= ys && o < ye;             // uniform: the pipeline is full and the row is the segment's
@@ -267,9 +303,9 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
             if constexpr (MODE == MODE_ITER) {
                 if constexpr (!(OFLK_LKS_ABL & 2))
                     if (o + 1 >= ys) pf_next = load_flow2(fin, row_e(o + 1));
-                issue_gathers((j + 1) % 3, r + 1);            // used by the next row, after this row's arithmetic
+                issue_gathers((jl + 1) % LD, r + 1);          // used by the next row, after this row's arithmetic
             }
-            issue_loads(j, r + LD);
+            issue_loads(jl, r + LD);
             __builtin_amdgcn_sched_barrier(0);
             // (prev + curr) / 2.0 and prev - curr, lucas_kanade_core.py:36, :43
             const float s0 = p.x + q.x, s1 = p.y + q.y;
@@ -336,12 +372,19 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
             for (int c = 0; c < 2; c++) {
                 float uu, vv;
                 if constexpr ((OFLK_LKS_ABL & 8) != 0) { uu = S[0][c] + S[1][c] + S[2][c]; vv = S[3][c] + S[4][c]; }
-                else lk_solve(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], uu, vv);
+                else if constexpr (MODE == MODE_SINGLE) {
+                    // Where the result is kept (integer frames in [0, 255], Sxx, Syy < 2^16 -- everything else is redone by the
+                    // tile kernel) the quotients' operands are in div2_shared_rcp's range: 1e-4 < |det| <= Sxx Syy < 2^32;
+                    // a numerator is the rounded difference of two exact multiples of 2^-12 (sums are multiples of 2^-8 and
+                    // 2^-4) below 2^16 * 2^20, hence 0 or at least 2^-12 and below 2^37.  In a tile that is redone anyway the
+                    // values written here do not matter.
+                    lk_solve<true>(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], uu, vv);
+                } else lk_solve(S[0][c], S[1][c], S[2][c], S[3][c], S[4][c], uu, vv);
                 const bool interior = oky && (c ? in1 : in0);
                 du[c] = interior ? uu : 0.0f;
                 dv[c] = interior ? vv : 0.0f;
                 if constexpr (MODE == MODE_SINGLE) {
-                    if (interior && lane_out && o_live && !(S[0][c] < kLksExactBound && S[1][c] < kLksExactBound)) inexact |= 1u;
+                    if (interior && o_live && !(S[0][c] < kLksExactBound && S[1][c] < kLksExactBound)) inexact |= 1u;
                 }
                 if constexpr (MODE == MODE_ITER) {
                     if (lane_out && o_live) {   // halo lanes repeat their neighbours' pixels
@@ -386,21 +429,29 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
                 }
             }
             if constexpr (MODE == MODE_SINGLE) {
-                // one flag per 64 x 24 tile of k_lkw's grid (a.redo: [B][tiles_y][tiles_x] bytes): at the last output row of
-                // a tile row and at the end of the segment the lanes that saw an inexact window mark their tiles
+                // at the last output row of a tile row and at the end of the segment the doubtful windows of the last rows go
+                // to the redo list (LkArgs::redo), tile by tile: the wave's columns reach at most four tile columns; a lane
+                // vouches for the columns three either side of its pair (a superset of the windows its pixels are in)
                 if (a.redo != nullptr && o_live && (((o + 1) % k5TY) == 0 || o == ye - 1)) {
-                    if (inexact && lane_out && x < W) {
-                        const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
-                        unsigned char *flags = a.redo + ((size_t)b * tiles_y + (size_t)(o / k5TY)) * tiles_x;
-                        flags[x / k5TX] = 1;
-                        flags[min(x + 1, Wm1) / k5TX] = 1;
+                    const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
+                    const int tlo = min(max(x - 3, 0), Wm1) / k5TX, thi = min(max(x + 4, 0), Wm1) / k5TX;
+                    const int t_first = min(max(xw - 3, 0), Wm1) / k5TX, t_last = min(max(xw + 131, 0), Wm1) / k5TX;
+                    const unsigned T = (unsigned)(a.B * tiles_y * tiles_x);
+                    for (int t = t_first; t <= t_last; t++) {   // uniform bounds
+                        if (__ballot(inexact != 0u && (tlo == t || thi == t)) != 0ull && lane == 0) {
+                            const unsigned tile = (unsigned)((b * tiles_y + o / k5TY) * tiles_x + t);
+                            if (__hip_atomic_exchange(&a.redo[2u + tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                const unsigned e = __hip_atomic_fetch_add(&a.redo[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                a.redo[2u + T + e] = tile;
+                            }
+                        }
                     }
                     inexact = 0u;
                 }
             }
         });
         if constexpr (MODE == MODE_ITER) {
-            // six fp32 terms per lane, then fp64 (what k_lkw does per thread and tile)
+            // 2 LD fp32 terms per lane, then fp64 (k_lkw: six per thread and tile)
             dsu += (double)su;
             dsv += (double)sv;
             su = 0.0f;

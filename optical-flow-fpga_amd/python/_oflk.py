@@ -73,6 +73,7 @@ SIGNATURES = {
     "oflk_plan_read_log": (ctypes.c_int, [_vp, _f32p, _i32p, _vp]),
     "oflk_plan_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_plan_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "oflk_plan_set_kernels": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _vp]),
     "oflk_flow_metrics": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "oflk_plan_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
@@ -228,6 +229,10 @@ class Plan:
     def set_arithmetic(self, mode: int) -> None:
         """0 = exact (default: the reference's values), 1 = contracted (opt-in: fused multiply-adds in the Gaussian pyramid)."""
         check(lib().oflk_plan_set_arithmetic(self._h, int(mode)))
+
+    def set_kernels(self, choice: int) -> None:
+        """0: automatic (5x5 single-scale streams, doubtful tiles redone in NumPy's order); 1: the tile kernel throughout"""
+        check(lib().oflk_plan_set_kernels(self._h, int(choice)))
 
     def set_profiling(self, enabled) -> None:
         """False/0 off, True/1 every kernel, 2 only the dominant kernel (finest-level LK iteration)."""

@@ -140,3 +140,87 @@ def test_tolerant_mode_within_tolerance_of_the_reference(golden_dir):
     out = Path(__file__).resolve().parents[1] / "gpurun_out"
     out.mkdir(exist_ok=True)
     (out / "tolerant_epe.json").write_text(json.dumps({"mean_epe_vs_reference": report, "max": max(report.values()), "bar": TOL}, indent=1))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# single-scale 5x5: the streaming kernel is EXACT on integer-valued frames (its window sums are exact in any order
+# while Sxx, Syy < 2^16) and hands every doubtful tile to the NumPy-order tile kernel within the same call
+# ---------------------------------------------------------------------------------------------------------------
+def _single(plan, p, c, u8=False):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    tp, tc = torch.from_numpy(p).to(dev), torch.from_numpy(c).to(dev)
+    u = torch.empty(p.shape, dtype=torch.float32, device=dev)
+    v = torch.empty_like(u)
+    (plan.single_scale_u8 if u8 else plan.single_scale)(tp.data_ptr(), tc.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+    torch.cuda.synchronize()
+    return u.cpu().numpy(), v.cpu().numpy()
+
+
+def _frames(kind, rng, H, W):
+    from oflk_synth import synth_pair
+
+    if kind == "synth":           # textured 8-bit frames: every window inside the bound
+        return synth_pair(H, W, int(rng.integers(0, 1000)))
+    if kind == "noise":           # white 8-bit noise
+        a = rng.integers(0, 256, (H, W)).astype(np.float32)
+        return a, np.roll(a, (1, 2), axis=(0, 1))
+    if kind == "edges":           # 0 / 255 blocks: Sxx reaches 4e5, far over 2^16 -- those tiles must come from the tile kernel
+        a = (255.0 * ((np.add.outer(np.arange(H) // 7, np.arange(W) // 5) % 2))).astype(np.float32)
+        a[H // 3:, :] = rng.integers(0, 256, (H - H // 3, W)).astype(np.float32)
+        return a, np.roll(a, (2, 1), axis=(0, 1))
+    if kind == "fractional":      # not integers at all: no window may keep the streaming kernel's sums
+        a = (rng.random((H, W)) * 255.0).astype(np.float32)
+        return a, (np.roll(a, (1, 1), axis=(0, 1)) * np.float32(0.97)).astype(np.float32)
+    # one non-integral pixel and one out-of-range pixel in otherwise 8-bit frames: only the windows they touch are in doubt
+    a, b = synth_pair(H, W, int(rng.integers(0, 1000)))
+    a = a.copy(); b = b.copy()
+    a[H // 2, W // 3] += np.float32(0.5)
+    b[min(H - 1, 5), W - 1] = np.float32(300.0)
+    a[0, 0] = np.float32(-1.0)
+    return a, b
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (241, 323), (97, 130), (24, 64), (25, 121), (1080, 1920)])
+@pytest.mark.parametrize("kind", ["synth", "noise", "edges", "fractional", "speckled"])
+def test_single_scale_streaming_path_is_exact(oracle, shape, kind):
+    """oflk_plan_single_scale, 5x5, automatic kernel choice == the oracle value for value, for every kind of frame: the
+    doubtful tiles (bound exceeded, non-integral or out-of-range pixels) are redone in NumPy's order inside the call"""
+    import _oflk
+
+    H, W = shape
+    rng = np.random.default_rng(7 * H + W)
+    p, c = _frames(kind, rng, H, W)
+    ou, ov = oracle.lucas_kanade_single_scale(p, c, 5)
+    plan = _oflk.Plan(0, 2, H, W, 1, 5, 0)
+    pp, cc = np.stack([p, c]), np.stack([c, p])        # two pairs per call (the second one reversed)
+    for choice in (0, 1, 0):
+        plan.set_kernels(choice)
+        u, v = _single(plan, pp, cc)
+        assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), (shape, kind, choice)
+    ru, rv = oracle.lucas_kanade_single_scale(c, p, 5)
+    assert np.array_equal(u[1], ru) and np.array_equal(v[1], rv)
+    if kind in ("synth", "noise", "edges"):
+        u8, v8 = _single(plan, pp.astype(np.uint8), cc.astype(np.uint8), u8=True)
+        assert np.array_equal(u8[0], ou) and np.array_equal(v8[0], ov) and np.array_equal(u8[1], ru)
+    plan.close()
+
+
+def test_single_scale_bound_of_the_exactness_argument(oracle):
+    """the worst frames the argument admits: two-level images whose windows sit just under / just over Sxx = 2^16 (a step
+    edge of height h gives Sxx = 2.5 h^2 per window row crossing it): flow equals the oracle's on both sides of the bound"""
+    import _oflk
+
+    H, W = 96, 192
+    for h in (150, 160, 161, 162, 163, 170, 255):
+        a = np.zeros((H, W), np.float32)
+        a[:, W // 2:] = h
+        a[H // 2:, : W // 4] = h
+        b = np.roll(a, (1, 1), axis=(0, 1))
+        ou, ov = oracle.lucas_kanade_single_scale(a, b, 5)
+        plan = _oflk.Plan(0, 1, H, W, 1, 5, 0)
+        u, v = _single(plan, a[None], b[None])
+        assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), h
+        plan.close()
