@@ -306,6 +306,9 @@ def main() -> None:
     ap.add_argument("--multi", default="ranks", choices=["ranks", "inproc"],
                     help="N > 1: one process per GPU (default) or ONE process with a plan per GPU")
     ap.add_argument("--no-parity", action="store_true", help="skip the 13-pattern EPE check after the timed region")
+    ap.add_argument("--gather", action="store_true",
+                    help="after the timed region: gather the flow shards of all ranks to rank 0 through the process group "
+                         "(RCCL on device tensors) and report gather_ms / gather_GBs next to, never inside, `value`")
     args = ap.parse_args()
     if args.gpus > 1 and args.multi == "ranks" and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:]))   # before torch / the GPU are touched
@@ -331,7 +334,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # backend "nccl" is RCCL on ROCm (device tensors); gloo reduces host tensors; no-op for one rank
-    group = Group(args.backend, dev if args.backend == "nccl" else None)
+    group = Group(args.backend, dev if args.backend == "nccl" else None, always=args.gather)   # --gather: RCCL even for one rank
 
     import _oflk
     from oflk_synth import synth_pair
@@ -637,6 +640,23 @@ def main() -> None:
                 parity["workload_pair0"] = {"flow_fields": 2, "digests_equal": eq, "mean_epe": 0.0 if eq == 2 else None,
                                             "source": f"tests/golden/reference_fullsize.json[{key}]: the reference's own flow of pair 0 "
                                                       f"of this workload ({c['reference_seconds']} s on one core there)"}
+    # ---- optional: the flow shards to rank 0 over the process group (reported separately) ----
+    gathered = None
+    if args.gather:
+        from oflk_dist import gather_flows
+
+        lays = [job_layout(args.config, r, world, args.pairs, args.height, args.width) for r in range(world)]
+        if args.backend == "nccl":
+            g = gather_flows(group, u, v, lays, torch.cuda.synchronize)
+        else:   # rehearsal: gloo moves host tensors
+            g = gather_flows(group, u.cpu(), v.cpu(), lays, torch.cuda.synchronize)
+        gathered = {"gather_ms": round(g["gather_ms"], 3), "gather_GBs": round(g["gather_GBs"], 2), "bytes_received_by_rank0": g["bytes_received"],
+                    "pairs": g["pairs"], "backend": args.backend,
+                    "note": "one gather collective of the [2][pairs][H][W] float32 shards to rank 0 after the timed region; not part of `value`"}
+        if rank == 0:
+            gathered["checksum_abs_u"] = float(g["u"].abs().sum(dtype=torch.float64).item())   # equals the SUM all-reduce of the ranks' totals
+            gathered["equals_allreduce_total"] = bool(abs(gathered["checksum_abs_u"] - job["sums"]["abs_u"]) <= 1e-9 * max(job["sums"]["abs_u"], 1.0))
+        del g
     if rank == 0:
         out = {
             "metric": "Mpix/s dense flow (1080p pyramidal)" if (H, W) == (1080, 1920) else "Mpix/s dense flow",
@@ -663,6 +683,7 @@ def main() -> None:
             "job_stats": job_stats,
             "contracted_arithmetic": contracted,
             "tolerance_mode": tolerant,
+            "gather": gathered,
             "one_pair_per_call": one_pair,
             "cpu_baseline": cpu,
             "epe_vs_reference": parity,

@@ -78,6 +78,15 @@ int oflk_pyramid_level_dims(int H, int W, int levels, double scale_factor, int *
 int oflk_build_pyramid(const float *image, int H, int W, int levels, double scale_factor,
                        float *const *out_levels);
 
+/* The same with the Gaussian weights given by the caller: weights[k], k = 0 .. radius, is the normalised weight at distance k
+ * of scipy.ndimage.gaussian_filter's kernel for sigma = 1 / scale_factor (radius = int(4 sigma + 0.5)).  SciPy forms them with
+ * NumPy's exp, whose last bit differs from libm's for some arguments; oflk_build_pyramid embeds SciPy's table for the
+ * reference's default scale_factor 0.5 and falls back to libm elsewhere.  The Python shim computes the weights with NumPy the
+ * way SciPy does (lucas_kanade_pyramidal.build_gaussian_pyramid) and calls this entry point, so EVERY scale factor gives the
+ * reference's pyramid (tests/golden/pyramid_scales*.npz, made by importing the reference). */
+int oflk_build_pyramid_w(const float *image, int H, int W, int levels, double scale_factor, const double *weights,
+                         int radius, float *const *out_levels);
+
 /* warp_image(image, flow_u, flow_v) -> warped
  * replaces python/lucas_kanade_pyramidal.py:66-97 */
 int oflk_warp(const float *image, const float *flow_u, const float *flow_v, int H, int W,
@@ -140,11 +149,13 @@ int oflk_single_scale_fp16(const float *prev, const float *curr, int B, int H, i
 
 /* ---- one process, several GPUs ------------------------------------------------- */
 /* Frame pairs are independent units (python/lucas_kanade_pyramidal.py:141-228 touches only its two
- * inputs), so a batch shards over GPUs with no data-path exchange: the B pairs are cut into n_gpus
- * contiguous shards (oflk_shard_range), shard g runs on device g in a host thread of its own with
- * its own plan, and every shard writes its slice of the host output arrays.  n_gpus <= 0 means all
- * visible devices; n_gpus > visible devices is OFLK_ERR_INVALID; with n_gpus == 1 the call is
- * oflk_*_batch on the device of oflk_set_device.  Results do not depend on n_gpus.
+ * inputs), so a batch spreads over GPUs with no data-path exchange.  How long a pair takes depends on its
+ * data (the early exit of :221-223), so devices do not get fixed shards: the B pairs are cut into chunks of
+ * consecutive pairs (about four per device) and each device -- a host thread of its own, its own plans --
+ * pulls the next chunk from a shared counter until none is left; every chunk is written to its slice of
+ * the host output arrays.  n_gpus <= 0 means all visible devices; n_gpus > visible devices is
+ * OFLK_ERR_INVALID; with n_gpus == 1 the call is oflk_*_batch on the device of oflk_set_device.  Results
+ * do not depend on n_gpus, nor on which device took which chunk.
  * (The multi-process form -- one rank per GPU, torch.distributed over RCCL -- is bench.py's.) */
 int oflk_single_scale_batch_multi(const float *prev, const float *curr, int B, int H, int W,
                                   int window_size, int n_gpus, float *u, float *v);
@@ -154,6 +165,10 @@ int oflk_pyramidal_batch_multi(const float *prev, const float *curr, int B, int 
 int oflk_pyramidal_u8_multi(const unsigned char *prev, const unsigned char *curr, int B, int H, int W,
                             int levels, int window_size, int iters, int n_gpus, float *u, float *v,
                             float *residual_log, int *iters_run);
+/* Rehearsal of the chunk queue above on a box with fewer GPUs than workers (tests): `workers` > 0 makes the *_multi entry
+ * points run that many queue workers, worker i on device i % n_gpus (workers of one device take turns on it); 0 restores
+ * one worker per device.  Results do not change. */
+int oflk_multi_rehearsal(int workers);
 /* [begin, end) of `total` units owned by shard `shard` of `n_shards` (contiguous, sizes differ by at
  * most one): the partition used above and by bench.py's ranks */
 void oflk_shard_range(int total, int shard, int n_shards, int *begin, int *end);
@@ -250,7 +265,7 @@ int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, fl
  * Measured against dense flows of the reference itself (tests/golden/dense_reference_flows.npz): worst of the 13
  * verification patterns 1.7e-5 px (translate_extreme), the 1080p bench pair 5.6e-7 px.  The arithmetic is stated on the
  * CPU by oracle/oflk_tolerant_model.c (test infrastructure) and the kernels are held to that statement bit for bit
- * (tests/test_gpu_tolerant.py), so the tolerance is a property of one written-down arithmetic, not of a GPU run.
+ * (tests/test_gpu_round4.py), so the tolerance is a property of one written-down arithmetic, not of a GPU run.
  * In both opt-in modes the exit-decision flags keep their meaning, and oflk_plan_resolve_uncertain redoes a flagged pair in
  * EXACT arithmetic from the caller's frames (its own exact pyramid): a redone pair is the reference's result, which is
  * inside any tolerance.  Windows without a fused iteration kernel (1x1, 13x13 ...) always run exactly. */

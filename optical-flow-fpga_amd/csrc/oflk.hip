@@ -53,6 +53,7 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 std::atomic<int> g_device{0};   // device of the host-pointer entry points (oflk_set_device)
+std::atomic<int> g_multi_workers{0};   // oflk_multi_rehearsal: queue workers of the *_multi entry points (0 = one per device)
 
 int ensure_device(int dev)
 {
@@ -1241,6 +1242,13 @@ OFLK_API int oflk_plan_set_arithmetic(oflk_plan *p, int mode)
     return OFLK_OK;
 }
 
+OFLK_API int oflk_multi_rehearsal(int workers)
+{
+    if (workers < 0 || workers > 64) return fail(OFLK_ERR_INVALID, "workers must be 0 ... 64, got %d", workers);
+    g_multi_workers.store(workers);
+    return OFLK_OK;
+}
+
 OFLK_API int oflk_plan_set_kernels(oflk_plan *p, int choice)
 {
     if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
@@ -1408,10 +1416,14 @@ int host_u8(HostCtx &c, size_t need)
 
 int host_ring(HostCtx &c, size_t in_bytes, size_t out_elems)
 {
-    if (!c.s_in) {
-        HIP_TRY(hipStreamCreateWithFlags(&c.s_in, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c.s_comp, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c.s_out, hipStreamNonBlocking));
+    // each stream on its own: a call that failed half-way here must not leave a later one on the null (blocking) stream
+    for (hipStream_t *st : {&c.s_in, &c.s_comp, &c.s_out}) {
+        if (*st) continue;
+        hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            *st = nullptr;
+            return fail(OFLK_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+        }
     }
     size_t tot = 0;
     if (in_bytes > c.ring_in_bytes) {
@@ -1479,8 +1491,16 @@ int run_batch_chunked(HostCtx *c, int dev, const PIXELS *prev, const PIXELS *cur
     oflk_plan *pc = nullptr, *pt = nullptr;
     if ((rc = host_plan(*c, dev, C, H, W, Lp, window_size, Kp, &pc))) return rc;
     const int tail = B - (nchunk - 1) * C;
-    if (tail != C && (rc = host_plan(*c, dev, tail, H, W, Lp, window_size, Kp, &pt))) return rc;
-    if (tail != C && (rc = host_plan(*c, dev, C, H, W, Lp, window_size, Kp, &pc))) return rc;   // (the cache may have moved it)
+    if (tail != C) {
+        // Both plans must be alive at once.  A lookup that runs out of device memory frees EVERY cached plan (host_plan), the
+        // other one of this pair included, so after the second lookup the first is looked up again and both are checked
+        // against the cache; if the two do not fit the device together the batch cannot run chunked.
+        if ((rc = host_plan(*c, dev, tail, H, W, Lp, window_size, Kp, &pt))) return rc;
+        if ((rc = host_plan(*c, dev, C, H, W, Lp, window_size, Kp, &pc))) return rc;
+        auto cached = [&](const oflk_plan *q) { return std::find(c->plans.begin(), c->plans.end(), q) != c->plans.end(); };
+        if (!cached(pc) || !cached(pt))
+            return fail(OFLK_ERR_NOMEM, "the chunk plan (%d pairs) and the tail plan (%d pairs) of %dx%d do not fit the device together", C, tail, W, H);
+    }
 
     hipEvent_t ev_in[2] = {nullptr, nullptr};   // a slot's frames have arrived
     for (int i = 0; i < 2; i++) {
@@ -1663,9 +1683,11 @@ void shard_range(int total, int i, int n, int *begin, int *end)
     *end = *begin + base + (i < extra ? 1 : 0);
 }
 
-// Frame pairs are independent units (lucas_kanade_pyramidal.py:141-228 touches only its two inputs):
-// the batch is cut into n_gpus contiguous shards, each run by its own host thread on its own device
-// with its own plan; no data crosses between devices.
+// Frame pairs are independent units (lucas_kanade_pyramidal.py:141-228 touches only its two inputs), and how long one
+// takes depends on its data (the early exit of :221-223 ends a level after one iteration or after all of them), so the
+// devices do not get fixed shards: the batch is cut into chunks of consecutive pairs and every device's host thread pulls
+// the next chunk from a shared counter until none is left -- a device whose pairs converge early simply takes more chunks.
+// No data crosses between devices, and a pair's result does not depend on which device computed it or in which chunk.
 template <class PIXELS>
 int run_batch_multi(const PIXELS *prev, const PIXELS *curr, int B, int H, int W, int levels, int window_size, int iters,
                     int n_gpus, float *u, float *v, float *residual_log, int *iters_run)
@@ -1678,34 +1700,48 @@ int run_batch_multi(const PIXELS *prev, const PIXELS *curr, int B, int H, int W,
     if (ndev < 1) return fail(OFLK_ERR_NO_DEVICE, "no usable HIP device; liboflk has no CPU path");
     if (n_gpus <= 0) n_gpus = ndev;
     if (n_gpus > ndev) return fail(OFLK_ERR_INVALID, "n_gpus = %d but %d device(s) visible", n_gpus, ndev);
-    n_gpus = std::min(n_gpus, B);   // never more shards than pairs
-    if (n_gpus == 1)
+    const int rehearsal = g_multi_workers.load();
+    int workers_n = rehearsal > 0 ? rehearsal : n_gpus;
+    workers_n = std::min(workers_n, B);   // never more workers than pairs
+    if (workers_n == 1)
         return run_batch_on<PIXELS>(g_device.load(), prev, curr, B, H, W, levels, window_size, iters, u, v, residual_log,
                                     iters_run);
     const size_t plane = (size_t)H * W;
     const int Lc = std::max(levels, 1), Kc = std::max(iters, 1);
-    std::vector<int> codes((size_t)n_gpus, OFLK_OK), redone((size_t)n_gpus, 0);
-    std::vector<std::string> msgs((size_t)n_gpus);
+    // chunks: about four per worker, so that the last ones even out what the data made uneven; at least one pair
+    const int chunk = std::max(1, (B + 4 * workers_n - 1) / (4 * workers_n));
+    std::atomic<int> next{0};
+    std::vector<int> codes((size_t)workers_n, OFLK_OK), redone((size_t)workers_n, 0);
+    std::vector<std::string> msgs((size_t)workers_n);
+    std::atomic<bool> failed{false};
     std::vector<std::thread> workers;
-    for (int g = 0; g < n_gpus; g++) {
+    for (int g = 0; g < workers_n; g++) {
         workers.emplace_back([&, g]() {
-            int b0, b1;
-            shard_range(B, g, n_gpus, &b0, &b1);
-            if (b1 <= b0) return;
-            const size_t off = (size_t)b0 * plane;
-            codes[(size_t)g] = run_batch_on<PIXELS>(g, prev + off, curr + off, b1 - b0, H, W, levels, window_size, iters,
-                                                    u + off, v + off,
-                                                    residual_log ? residual_log + (size_t)b0 * Lc * Kc * 2 : nullptr,
-                                                    iters_run ? iters_run + (size_t)b0 * Lc : nullptr);
-            if (codes[(size_t)g]) msgs[(size_t)g] = t_err;   // the worker's thread-local message
-            redone[(size_t)g] = t_resolved;                    // ... and its count of pairs redone
+            const int dev = g % n_gpus;
+            while (!failed.load()) {
+                const int b0 = next.fetch_add(chunk);
+                if (b0 >= B) break;
+                const int b1 = std::min(b0 + chunk, B);
+                const size_t off = (size_t)b0 * plane;
+                const int c = run_batch_on<PIXELS>(dev, prev + off, curr + off, b1 - b0, H, W, levels, window_size, iters,
+                                                   u + off, v + off,
+                                                   residual_log ? residual_log + (size_t)b0 * Lc * Kc * 2 : nullptr,
+                                                   iters_run ? iters_run + (size_t)b0 * Lc : nullptr);
+                redone[(size_t)g] += t_resolved;                  // the worker's count of pairs redone
+                if (c) {
+                    codes[(size_t)g] = c;
+                    msgs[(size_t)g] = t_err;                      // the worker's thread-local message
+                    failed.store(true);                           // the others stop after their current chunk
+                    break;
+                }
+            }
         });
     }
     for (auto &w : workers) w.join();
     t_resolved = 0;
-    for (int g = 0; g < n_gpus; g++) t_resolved += redone[(size_t)g];
-    for (int g = 0; g < n_gpus; g++)
-        if (codes[(size_t)g]) return fail(codes[(size_t)g], "device %d: %s", g, msgs[(size_t)g].c_str());
+    for (int g = 0; g < workers_n; g++) t_resolved += redone[(size_t)g];
+    for (int g = 0; g < workers_n; g++)
+        if (codes[(size_t)g]) return fail(codes[(size_t)g], "device %d: %s", g % n_gpus, msgs[(size_t)g].c_str());
     return OFLK_OK;
 }
 
@@ -2052,8 +2088,29 @@ OFLK_API int oflk_from_gradients(const float *Ix, const float *Iy, const float *
     return OFLK_OK;
 }
 
+namespace {
+int build_pyramid_host(const float *image, int H, int W, int levels, double scale_factor, const GaussW *given, float *const *out_levels);
+}
+
 OFLK_API int oflk_build_pyramid(const float *image, int H, int W, int levels, double scale_factor,
                                 float *const *out_levels)
+{
+    return build_pyramid_host(image, H, W, levels, scale_factor, nullptr, out_levels);
+}
+
+OFLK_API int oflk_build_pyramid_w(const float *image, int H, int W, int levels, double scale_factor, const double *weights,
+                                  int radius, float *const *out_levels)
+{
+    if (!weights) return fail(OFLK_ERR_INVALID, "NULL weights");
+    if (radius < 0 || radius > kMaxRadius) return fail(OFLK_ERR_UNSUPPORTED, "gaussian radius %d outside [0, %d]", radius, kMaxRadius);
+    GaussW g;
+    g.radius = radius;
+    for (int k = 0; k <= radius; k++) g.w[k] = weights[k];
+    return build_pyramid_host(image, H, W, levels, scale_factor, &g, out_levels);
+}
+
+namespace {
+int build_pyramid_host(const float *image, int H, int W, int levels, double scale_factor, const GaussW *given, float *const *out_levels)
 {
     int rc = check_hw(image, out_levels, H, W);
     if (rc) return rc;
@@ -2065,7 +2122,8 @@ OFLK_API int oflk_build_pyramid(const float *image, int H, int W, int levels, do
     std::unique_lock<std::mutex> lk;
     if ((rc = acquire(g_device.load(), &c, lk))) return rc;
     GaussW gauss;
-    if ((rc = make_gauss(1.0 / scale_factor, &gauss))) return rc;
+    if (given) gauss = *given;
+    else if ((rc = make_gauss(1.0 / scale_factor, &gauss))) return rc;
     Arena ar;
     size_t N = (size_t)H * W;
     float *cur = nullptr, *nxt = nullptr, *tA = nullptr, *tB = nullptr;
@@ -2085,6 +2143,7 @@ OFLK_API int oflk_build_pyramid(const float *image, int H, int W, int levels, do
     HIP_TRY(hipStreamSynchronize(nullptr));
     return OFLK_OK;
 }
+}  // namespace
 
 OFLK_API int oflk_warp(const float *image, const float *flow_u, const float *flow_v, int H, int W,
                        float *out)

@@ -39,6 +39,8 @@ SIGNATURES = {
     "oflk_single_scale": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
     "oflk_pyramid_level_dims": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _i32p]),
     "oflk_build_pyramid": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(_f32p)]),
+    "oflk_build_pyramid_w": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.c_int, ctypes.POINTER(_f32p)]),
     "oflk_warp": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, _f32p]),
     "oflk_upsample_flow": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]),
     "oflk_pyramidal": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]),
@@ -74,6 +76,7 @@ SIGNATURES = {
     "oflk_plan_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_plan_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_plan_set_kernels": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "oflk_multi_rehearsal": (ctypes.c_int, [ctypes.c_int]),
     "oflk_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _vp]),
     "oflk_flow_metrics": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "oflk_plan_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),

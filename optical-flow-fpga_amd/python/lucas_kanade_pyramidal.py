@@ -68,7 +68,17 @@ def build_gaussian_pyramid(
     shapes = pyramid_level_shapes((H, W), num_levels, scale_factor)
     levels = [np.empty(s, np.float32) for s in shapes]
     arr = (_f32p * num_levels)(*[_oflk.ptr(a) for a in levels])
-    _oflk.check(_oflk.lib().oflk_build_pyramid(_oflk.ptr(img), H, W, int(num_levels), float(scale_factor), arr))
+    # The Gaussian weights as SciPy forms them (scipy/ndimage/_filters.py _gaussian_kernel1d: NumPy's exp, normalised by
+    # the kernel's sum), handed to the library: its own fallback for sigma != 2 is libm's exp, which differs from NumPy's
+    # in the last bit for some arguments.  With the caller's weights every scale factor gives the reference's values.
+    sigma = 1.0 / float(scale_factor)   # :46
+    radius = int(4.0 * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    w = np.ascontiguousarray(phi[radius:], np.float64)
+    _oflk.check(_oflk.lib().oflk_build_pyramid_w(_oflk.ptr(img), H, W, int(num_levels), float(scale_factor),
+                                                 w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), radius, arr))
     return levels
 
 

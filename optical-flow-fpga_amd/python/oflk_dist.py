@@ -4,8 +4,9 @@ Frame pairs are independent units (reference lucas_kanade_pyramidal.py:141-228
 touches only its two inputs), so the data path needs NO collective: every rank
 runs the same plan on its own pairs.  torch.distributed (backend "nccl" = RCCL
 over xGMI on the GPU box, "gloo" in CPU tests) is used only for the barrier that
-brackets a timed region, the MAX over ranks of the elapsed time, and an optional
-gather of small per-rank summaries to rank 0.
+brackets a timed region, the MAX over ranks of the elapsed time, a gather of small
+per-rank summaries to rank 0 and -- optional, after the timed region, reported on its
+own -- the gather of the flow shards themselves (gather_flows).
 """
 from __future__ import annotations
 
@@ -158,3 +159,39 @@ def job_throughput(group: "Group", layout: JobLayout, steps: int, elapsed_max: f
     sums = {k: group.sum_over_ranks(float(v)) for k, v in sorted(local_sums.items())}
     pix = float(pairs_all) * layout.height * layout.width * steps
     return {"pairs_per_step": pairs_all, "Mpix_per_s": pix / elapsed_max / 1e6, "sums": sums}
+
+
+def gather_flows(group: "Group", u, v, layouts: List[JobLayout], device_sync: Callable[[], None], dst: int = 0
+                 ) -> Dict[str, Any]:
+    """The flow shards of all ranks to rank `dst`, as ONE collective on the group's backend (RCCL gather on device tensors,
+    gloo on host tensors in the tests): never part of the compute time -- bench.py runs it after the timed region and reports
+    it on its own.  u, v: this rank's [pairs_local, H, W] float32 tensors (on the group's device); layouts: the JobLayout of
+    every rank (job_layout is a pure function of rank and world, so every rank can list them).
+    Returns {"gather_ms", "gather_GBs", "bytes_received", "pairs"} and, on `dst`, "u" / "v": [pairs_total, H, W] tensors in
+    job order.  A gather wants equal pieces: shards are padded to the largest one (they differ by at most one pair)."""
+    import torch
+
+    me = layouts[group.rank]
+    n_max = max(l.pairs_local for l in layouts)
+    H, W = me.height, me.width
+    send = torch.zeros((2, n_max, H, W), dtype=torch.float32, device=u.device)
+    send[0, :me.pairs_local].copy_(u)
+    send[1, :me.pairs_local].copy_(v)
+    pieces = [torch.empty_like(send) for _ in layouts] if group.rank == dst else None
+    device_sync()
+    group.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    if group.dist is not None:
+        group.dist.gather(send, pieces, dst=dst)
+    else:
+        pieces[0].copy_(send)
+    device_sync()
+    elapsed = group.max_over_ranks(time.perf_counter() - t0)
+    received = sum(2 * l.pairs_local * H * W * 4 for r, l in enumerate(layouts) if r != dst)   # useful bytes that crossed ranks
+    out: Dict[str, Any] = {"gather_ms": 1e3 * elapsed, "gather_GBs": received / elapsed / 1e9 if elapsed > 0 else 0.0,
+                           "bytes_received": received, "pairs": sum(l.pairs_local for l in layouts)}
+    if group.rank == dst:
+        out["u"] = torch.cat([pieces[r][0, :l.pairs_local] for r, l in enumerate(layouts)])
+        out["v"] = torch.cat([pieces[r][1, :l.pairs_local] for r, l in enumerate(layouts)])
+    return out

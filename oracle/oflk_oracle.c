@@ -338,6 +338,18 @@ static void correlate1d_sym(const float *in, float *out, int nlines, int len, si
     }
 }
 
+/* gaussian_filter with the caller's weights (w[k] at distance k, k = 0..radius): what SciPy computes once it has
+ * its kernel.  The Python wrapper forms the kernel with NumPy exactly as scipy/ndimage/_filters.py
+ * _gaussian_kernel1d does (np.exp, not libm's exp), which pins every sigma, not only the embedded sigma = 2. */
+OFLK_EXPORT void oflk_oracle_gaussian_filter_w(const float *in, int H, int W, const double *w, int radius, float *out)
+{
+    size_t N = (size_t)H * (size_t)W;
+    float *tmp = (float *)malloc(sizeof(float) * (N ? N : 1));
+    correlate1d_sym(in, tmp, W, H, 1, (size_t)W, w, radius);
+    correlate1d_sym(tmp, out, H, W, (size_t)W, 1, w, radius);
+    free(tmp);
+}
+
 /* gaussian_filter(image_f32, sigma): axis 0 first, fp32 store, then axis 1. */
 OFLK_EXPORT void oflk_oracle_gaussian_filter(const float *in, int H, int W, double sigma, float *out)
 {
@@ -451,6 +463,24 @@ OFLK_EXPORT void oflk_oracle_build_pyramid(const float *img, int H, int W, int l
         float *sm = (float *)malloc(sizeof(float) * (n ? n : 1));
         oflk_oracle_gaussian_filter(out[l + 1], h, w, sigma, sm);    /* :47 */
         oflk_oracle_resample_linspace(sm, h, w, ho, wo, out[l]);     /* :55-59 */
+        free(sm);
+    }
+}
+
+/* build_gaussian_pyramid with the caller's Gaussian weights (see oflk_oracle_gaussian_filter_w) */
+OFLK_EXPORT void oflk_oracle_build_pyramid_w(const float *img, int H, int W, int levels, double scale, const double *w,
+                                             int radius, float **out)
+{
+    int dims[2 * 32];
+    if (levels > 32) levels = 32;
+    oflk_oracle_pyramid_dims(H, W, levels, scale, dims);
+    memcpy(out[levels - 1], img, sizeof(float) * (size_t)H * (size_t)W);
+    for (int l = levels - 2; l >= 0; l--) {
+        int h = dims[2 * (l + 1)], wd = dims[2 * (l + 1) + 1];
+        size_t n = (size_t)h * (size_t)wd;
+        float *sm = (float *)malloc(sizeof(float) * (n ? n : 1));
+        oflk_oracle_gaussian_filter_w(out[l + 1], h, wd, w, radius, sm);
+        oflk_oracle_resample_linspace(sm, h, wd, dims[2 * l], dims[2 * l + 1], out[l]);
         free(sm);
     }
 }

@@ -61,6 +61,7 @@ def lib() -> ctypes.CDLL:
         L.oflk_oracle_upsample_flow.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p]
         L.oflk_oracle_pyramidal.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _i32p]
         L.oflk_oracle_pyramidal.restype = ctypes.c_int
+        L.oflk_oracle_build_pyramid_w.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _f64p, ctypes.c_int, ctypes.POINTER(_f32p)]
     return _lib
 
 
@@ -143,7 +144,29 @@ def pyramid_dims(H: int, W: int, num_levels: int, scale_factor: float = 0.5) -> 
     return [(d[2 * l], d[2 * l + 1]) for l in range(num_levels)]
 
 
+def scipy_gaussian_weights(sigma: float) -> np.ndarray:
+    """scipy/ndimage/_filters.py _gaussian_kernel1d(sigma, 0, int(4 sigma + 0.5)) restated with NumPy: the half kernel
+    w[k], k = 0..radius.  NumPy's exp, as SciPy uses -- libm's differs in the last ulp for some arguments."""
+    radius = int(4.0 * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:], np.float64)
+
+
 def build_gaussian_pyramid(image, num_levels: int, scale_factor: float = 0.5) -> List[np.ndarray]:
+    a = _c(image)
+    H, W = a.shape
+    dims = pyramid_dims(H, W, num_levels, scale_factor)
+    outs = [np.empty(d, np.float32) for d in dims]
+    arr = (_f32p * num_levels)(*[_p(o) for o in outs])
+    w = scipy_gaussian_weights(1.0 / float(scale_factor))
+    lib().oflk_oracle_build_pyramid_w(_p(a), H, W, num_levels, float(scale_factor), w.ctypes.data_as(_f64p), len(w) - 1, arr)
+    return outs
+
+
+def build_gaussian_pyramid_libm(image, num_levels: int, scale_factor: float = 0.5) -> List[np.ndarray]:
+    """the all-C form (weights from libm's exp unless sigma = 2): what the oracle was before round 4"""
     a = _c(image)
     H, W = a.shape
     dims = pyramid_dims(H, W, num_levels, scale_factor)

@@ -45,6 +45,11 @@ def pytest_collection_modifyitems(config, items):
     except Exception as e:   # library not built
         have, why = False, f"liboflk not loadable: {e}"
     if not have:
+        # An explicit `-m gpu` run (the GPU box's) or a machine that shows a GPU driver must FAIL here, not skip: a broken
+        # build or runtime would otherwise read as "all skipped, rc 0".  Only a plain run on a box without a GPU skips.
+        asked = "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or "")
+        if asked or os.path.exists("/dev/kfd"):
+            raise pytest.UsageError(f"GPU tests selected but the HIP path is unusable: {why}")
         skip = pytest.mark.skip(reason=why)
         for it in gpu_items:
             it.add_marker(skip)

@@ -167,3 +167,51 @@ def test_bench_refuses_a_world_size_mismatch():
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=300, env=env)
     assert out.returncode == 2 and "WORLD_SIZE=1" in out.stderr and not out.stdout.strip()
+
+
+# ---------------------------------------------------------------------------
+# optional gather of the flow shards (bench.py --gather): one collective, after the timed region
+# ---------------------------------------------------------------------------
+GATHER_WORKER = textwrap.dedent("""
+    import json, sys
+    sys.path.insert(0, {product!r})
+    import torch
+    from oflk_dist import Group, env_rank, gather_flows, job_layout
+    rank, local_rank, world = env_rank()
+    g = Group("gloo")
+    out = {{}}
+    for cfg, pairs in (("1080p", 3), ("4k64", None)):
+        lays = [job_layout(cfg, r, world, pairs, 6, 8) for r in range(world)]
+        if cfg == "4k64":
+            lays = [job_layout(cfg, r, world, None, 6, 8) for r in range(world)]
+            lays[1].pairs_local -= 1          # a ragged job: the second shard one pair shorter (padding path)
+        me = lays[rank]
+        idx = torch.arange(me.pair_begin, me.pair_begin + me.pairs_local, dtype=torch.float32)
+        u = idx[:, None, None].expand(me.pairs_local, 6, 8).contiguous()          # pair k's u is k everywhere
+        v = -u
+        r = gather_flows(g, u, v, lays, lambda: None)
+        if rank == 0:
+            out[cfg] = {{"pairs": r["pairs"], "ms": r["gather_ms"], "bytes": r["bytes_received"],
+                        "u_first": [float(x) for x in r["u"][:, 0, 0]], "v_ok": bool(torch.equal(r["v"], -r["u"])),
+                        "shape": list(r["u"].shape)}}
+    if rank == 0:
+        print("RESULT " + json.dumps(out))
+    g.close()
+""")
+
+
+def test_gather_of_flow_shards_two_ranks(tmp_path):
+    import json
+
+    script = tmp_path / "gather_worker.py"
+    script.write_text(GATHER_WORKER.format(product=str(ROOT / "optical-flow-fpga_amd" / "python")))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29575", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    # weak config: 3 pairs per rank, job order 0..5; bytes that crossed ranks = the second rank's shard
+    assert res["1080p"]["pairs"] == 6 and res["1080p"]["u_first"] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0] and res["1080p"]["v_ok"]
+    assert res["1080p"]["bytes"] == 2 * 3 * 6 * 8 * 4 and res["1080p"]["shape"] == [6, 6, 8]
+    # ragged: 32 + 31 pairs, the padding of the shorter shard never shows up
+    assert res["4k64"]["pairs"] == 63 and res["4k64"]["u_first"] == [float(i) for i in range(63)] and res["4k64"]["v_ok"]

@@ -143,7 +143,8 @@ def test_contracted_arithmetic_is_opt_in_and_close(golden_dir):
                                 "pyr_down_ratio": round(out[1][2] / out[0][2], 3), "step_ms_exact": round(out[0][3], 3),
                                 "step_ms_contracted": round(out[1][3], 3)}
     assert epe.mean() <= 1e-4
-    assert out[1][2] <= 0.95 * out[0][2], report["bench_1080p_x8"]   # 0.79 - 0.86 measured (8 pairs per launch; box to box)
+    # (timings are reported, not asserted: 0.79 - 0.86 measured for pyr_down_ratio, 8 pairs per launch, box to box -- a
+    # throttling box must not turn a correctness suite red)
     plan.close()
     outp = Path(__file__).resolve().parents[1] / "gpurun_out"
     outp.mkdir(exist_ok=True)
@@ -346,9 +347,10 @@ def test_batches_beyond_4_gib_address_every_pair(u8):
 # host entry points from several threads at once (one context and mutex per device; ctypes releases the GIL)
 # ---------------------------------------------------------------------------------------------
 def test_concurrent_host_calls_from_several_threads():
-    """Four threads call the drop-in functions at the same time on different shapes / modes (float32, uint8, single-scale,
-    pyramidal, a chunked batch through the C ABI): every result equals the one the same call gives on its own, and an
-    error raised in one thread (a window the library refuses) does not leak into the others' error state."""
+    """Five threads call the library at the same time on different shapes / modes (float32, uint8, single-scale, pyramidal
+    through the drop-in functions; a 16-pair 1080p batch through the C ABI, which takes the chunked path with its own copy
+    thread): every result equals the one the same call gives on its own, and an error raised in one thread (a window the
+    library refuses) does not leak into the others' error state."""
     import threading
 
     import _oflk
@@ -368,12 +370,36 @@ def test_concurrent_host_calls_from_several_threads():
         else:
             fn = lambda p=p, c=c: K.lucas_kanade_single_scale(p, c, 7)
         jobs.append(fn)
+    # fifth job: a batch large enough for the chunked path of the C ABI (16 pairs of 1080p = four chunks: H2D, kernels and
+    # D2H on three streams, a second host thread for the copies back), a refused call on the same shape in between
+    L = _oflk.lib()
+    bp, bc = _batch(np.random.default_rng(11), 2, 1080, 1920)
+    bp = np.ascontiguousarray(np.concatenate([bp] * 8))
+    bc = np.ascontiguousarray(np.concatenate([bc] * 8))
+
+    def chunked():
+        u = np.empty(bp.shape, np.float32)
+        v = np.empty_like(u)
+        runs = np.zeros((16, 3), np.int32)
+        try:
+            _oflk.check(L.oflk_pyramidal_batch(bp.ctypes.data_as(f32p), bc.ctypes.data_as(f32p), 16, 1080, 1920, 3, 101, 3,
+                                               u.ctypes.data_as(f32p), v.ctypes.data_as(f32p), None, runs.ctypes.data_as(i32p)))
+            raise AssertionError("window 101 was accepted by the batch entry point")
+        except _oflk.OflkError:
+            pass
+        _oflk.check(L.oflk_pyramidal_batch(bp.ctypes.data_as(f32p), bc.ctypes.data_as(f32p), 16, 1080, 1920, 3, 5, 3,
+                                           u.ctypes.data_as(f32p), v.ctypes.data_as(f32p), None, runs.ctypes.data_as(i32p)))
+        return u, v
+
+    jobs.append(chunked)
     want = [fn() for fn in jobs]
+    for k in range(2, 16):   # the chunked batch itself: every pair equals its twin in the first chunk
+        assert np.array_equal(want[4][0][k], want[4][0][k % 2]) and np.array_equal(want[4][1][k], want[4][1][k % 2])
     errors, mismatches = [], []
 
     def worker(k):
         try:
-            for rep in range(25):
+            for rep in range(25 if k < 4 else 3):
                 u, v = jobs[k]()
                 if not (np.array_equal(u, want[k][0]) and np.array_equal(v, want[k][1])):
                     mismatches.append((k, rep))

@@ -1,4 +1,11 @@
-"""GPU tests of the opt-in within-tolerance arithmetic (OFLK_ARITH_TOLERANT, include/oflk.h).
+"""GPU tests added in round 4 (run on an MI355X: python -m pytest tests -m gpu -x -q).
+
+  * the opt-in within-tolerance arithmetic (OFLK_ARITH_TOLERANT, include/oflk.h), below
+  * single-scale 5x5 through the streaming kernel: exact on 8-bit frames, doubtful tiles redone in NumPy's order
+  * oflk_*_multi: chunks of pairs pulled from a shared counter
+  * bench.py --gather: the flow shards to rank 0 through RCCL, reported next to the throughput
+
+The within-tolerance arithmetic:
 
 Two links, each sharp on its own:
   * HIP == CPU model, bit for bit: oracle/oflk_tolerant_model.c states the tolerant mode's arithmetic operation for operation
@@ -224,3 +231,98 @@ def test_single_scale_bound_of_the_exactness_argument(oracle):
         u, v = _single(plan, a[None], b[None])
         assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), h
         plan.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one process, several GPUs: chunks of pairs pulled from a shared counter (per-pair time is data-dependent)
+# ---------------------------------------------------------------------------------------------------------------
+def test_multi_chunk_queue_is_independent_of_who_takes_what(oracle):
+    """a batch mixing pairs that leave every level after one iteration (identical frames), pairs that leave early and
+    pairs that run every iteration, through oflk_pyramidal_batch_multi with 1 ... 5 queue workers (rehearsed on the
+    devices this box has): flow, residual log and iteration counts of every pair are those of a call of its own, whoever
+    took its chunk; the float32, the uint8 and the single-scale entry points"""
+    import ctypes
+
+    import _oflk
+    from oflk_synth import synth_pair, synth_pair_smooth
+
+    f32p = ctypes.POINTER(ctypes.c_float)
+    i32p = ctypes.POINTER(ctypes.c_int)
+    L_ = _oflk.lib()
+    H, W, L, K = 240, 320, 3, 4
+    pairs = []
+    for i in range(11):
+        if i % 3 == 0:
+            p, _ = synth_pair(H, W, i)
+            pairs.append((p, p.copy()))                       # exits after one iteration per level
+        elif i % 3 == 1:
+            pairs.append(synth_pair_smooth(H, W, i, 0.04, -0.02))   # leaves some levels early
+        else:
+            pairs.append(synth_pair(H, W, i))                 # runs everything
+    prev = np.ascontiguousarray(np.stack([p for p, _ in pairs]))
+    curr = np.ascontiguousarray(np.stack([c for _, c in pairs]))
+    B = len(pairs)
+    want = [oracle.lucas_kanade_pyramidal_ex(p, c, L, 5, K) for p, c in pairs]
+    assert len({tuple(w[3]) for w in want}) >= 3, "the batch should mix iteration counts"
+    try:
+        for workers in (0, 2, 3, 5):
+            _oflk.check(L_.oflk_multi_rehearsal(workers))
+            u, v = np.empty_like(prev), np.empty_like(prev)
+            log, runs = np.zeros((B, L, K, 2), np.float32), np.zeros((B, L), np.int32)
+            _oflk.check(L_.oflk_pyramidal_batch_multi(prev.ctypes.data_as(f32p), curr.ctypes.data_as(f32p), B, H, W, L, 5, K, 0,
+                                                      u.ctypes.data_as(f32p), v.ctypes.data_as(f32p), log.ctypes.data_as(f32p),
+                                                      runs.ctypes.data_as(i32p)))
+            for b, (wu, wv, wlog, wruns) in enumerate(want):
+                assert np.array_equal(u[b], wu) and np.array_equal(v[b], wv) and list(runs[b]) == list(wruns), (workers, b)
+        _oflk.check(L_.oflk_multi_rehearsal(4))
+        us, vs = np.empty_like(prev), np.empty_like(prev)
+        _oflk.check(L_.oflk_single_scale_batch_multi(prev.ctypes.data_as(f32p), curr.ctypes.data_as(f32p), B, H, W, 5, 0,
+                                                     us.ctypes.data_as(f32p), vs.ctypes.data_as(f32p)))
+        for b, (p, c) in enumerate(pairs):
+            ou, ov = oracle.lucas_kanade_single_scale(p, c, 5)
+            assert np.array_equal(us[b], ou) and np.array_equal(vs[b], ov), b
+        # a failing chunk stops the queue and reports its device
+        rc = L_.oflk_pyramidal_batch_multi(prev.ctypes.data_as(f32p), curr.ctypes.data_as(f32p), B, H, W, L, 101, K, 0,
+                                           us.ctypes.data_as(f32p), vs.ctypes.data_as(f32p), None, None)
+        assert rc != 0 and b"device" in L_.oflk_last_error()
+    finally:
+        _oflk.check(L_.oflk_multi_rehearsal(0))
+    assert L_.oflk_multi_rehearsal(-1) != 0
+
+
+def test_bench_gather_runs_over_rccl_with_the_rank_this_box_has():
+    """bench.py --gather: RCCL is initialised (one rank), the shard is gathered on device tensors after the timed region, the
+    gathered flow's checksum equals the all-reduced total, and `value` is computed without it"""
+    import os
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--pairs", "4", "--steps", "2", "--warmup", "1", "--gather",
+                          "--no-cpu-baseline", "--no-one-pair", "--no-live-traffic", "--no-parity"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    g = line["gather"]
+    assert g["backend"] == "nccl" and g["pairs"] == 4 and g["equals_allreduce_total"] is True and g["gather_ms"] > 0
+    assert line["value"] > 0 and line["n_gpus"] == 1
+
+
+MORE_SCALES = (0.35, 0.45, 0.55, 0.65, 0.8, 0.9, 0.25, 0.7, 1.0 / 3.0)
+
+
+@pytest.mark.parametrize("sf", MORE_SCALES)
+def test_pyramid_any_scale_factor_equals_the_reference(golden_dir, sf):
+    """build_gaussian_pyramid of the drop-in module at nine scale factors nobody tuned for: the shim hands SciPy's own
+    Gaussian weights (formed with NumPy) to oflk_build_pyramid_w, and the pyramid equals the reference's
+    (tests/golden/pyramid_scales_more.npz, made by importing it) value for value"""
+    import lucas_kanade_pyramidal as P
+
+    z = np.load(golden_dir / "pyramid_scales_more.npz")
+    levels = 3 if sf >= 0.3 else 2
+    pyr = P.build_gaussian_pyramid(z["image"], levels, scale_factor=sf)
+    assert len(pyr) == levels
+    for l, a in enumerate(pyr):
+        np.testing.assert_array_equal(np.asarray(a, np.float32), z[f"sf{sf!r}_level{l}"])

@@ -1,5 +1,5 @@
 """CPU tests of oracle/oflk_tolerant_model.c, the CPU statement of the library's opt-in OFLK_ARITH_TOLERANT arithmetic
-(test infrastructure; the GPU tests hold the HIP kernels to it bit for bit, tests/test_gpu_tolerant.py).
+(test infrastructure; the GPU tests hold the HIP kernels to it bit for bit, tests/test_gpu_round4.py).
 
   * with every switch off the model IS the oracle (same values)
   * the shipped assignment of switches stays within the north star's tolerance -- mean endpoint error <= 1e-4 px -- of
