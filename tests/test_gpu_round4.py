@@ -256,7 +256,7 @@ def test_multi_chunk_queue_is_independent_of_who_takes_what(oracle):
             p, _ = synth_pair(H, W, i)
             pairs.append((p, p.copy()))                       # exits after one iteration per level
         elif i % 3 == 1:
-            pairs.append(synth_pair_smooth(H, W, i, 0.04, -0.02))   # leaves some levels early
+            pairs.append(synth_pair_smooth(H, W, i, 0.1, 0.05))     # leaves its levels after 2, 2 and 3 of 4 iterations
         else:
             pairs.append(synth_pair(H, W, i))                 # runs everything
     prev = np.ascontiguousarray(np.stack([p for p, _ in pairs]))
