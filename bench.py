@@ -525,6 +525,11 @@ def main() -> None:
                                     "achieved": round(bpl / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(bpl / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": round(t_ms * 1e3, 2),
                                     "algorithmic_bytes_per_launch": bpl, "traffic": None}
+            trt = profile_file("hbm_traffic_tolerant", B, (H, W))
+            if trt:
+                tolerant["roofline"]["traffic"] = trt["hbm_bytes_per_launch"]
+                tolerant["roofline"]["traffic_source"] = (f"profiles/{trt['_file']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                                                         "this command (tools/profiles_r04.sh)")
         try:
             dense = np.load(ROOT / "tests" / "golden" / "dense_reference_flows.npz")
             z = np.load(ROOT / "tests" / "golden" / "patterns_320x240.npz")

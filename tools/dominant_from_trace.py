@@ -9,10 +9,11 @@ import json
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
+match = sys.argv[3] if len(sys.argv) > 3 else "k_lkw<"      # e.g. "k_lks<" for the streaming kernel of the tolerant mode
 rows = []
 for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_lkw<" in r["Kernel_Name"] and ", 1, " in r["Kernel_Name"]:
+        if match in r["Kernel_Name"] and (", 1, " in r["Kernel_Name"] or "<1, " in r["Kernel_Name"]):
             grid = int(r.get("Grid_Size") or 0) or int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
             rows.append((r["Kernel_Name"], grid, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 big = max(g for _, g, _ in rows)

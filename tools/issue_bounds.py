@@ -73,7 +73,7 @@ def static_mix(asm_path, kernel, prices):
     return tot, mean_cost, {k: by[k] / tot for k in by}
 
 
-def kernel_bounds(pmc_dir, match, kernel_sym, asm, prices, hbm_bytes_per_px=None):
+def kernel_bounds(pmc_dir, match, kernel_sym, asm, prices, hbm_bytes_per_px=None, waves_per_simd=WAVES_PER_SIMD):
     rows = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(dict)
     files = collections.defaultdict(list)
@@ -95,7 +95,7 @@ def kernel_bounds(pmc_dir, match, kernel_sym, asm, prices, hbm_bytes_per_px=None
     valu = c["SQ_INSTS_VALU"]
     total = valu + c.get("SQ_INSTS_SALU", 0) + c.get("SQ_INSTS_LDS", 0) + c.get("SQ_INSTS_VMEM_RD", 0) + c.get("SQ_INSTS_VMEM_WR", 0)
     pipe_cycles = valu * mean_cost / N_SIMD
-    cadence_cycles = total * CADENCE / (N_SIMD * WAVES_PER_SIMD)
+    cadence_cycles = total * CADENCE / (N_SIMD * waves_per_simd)
     return {
         "launch_us_under_pmc": round(us, 1), "clock_GHz": round(clock_ghz, 3),
         "wave_instructions_per_launch": {"valu": valu, "salu": c.get("SQ_INSTS_SALU"), "lds": c.get("SQ_INSTS_LDS"),
@@ -105,9 +105,9 @@ def kernel_bounds(pmc_dir, match, kernel_sym, asm, prices, hbm_bytes_per_px=None
         "valu_pipe": {"floor_us": round(pipe_cycles / clock_ghz / 1e3, 1), "frac": round(pipe_cycles / clock_ghz / 1e3 / us, 3),
                       "meaning": "vector-ALU time of the launch's instructions at the saturated, wall-clock-validated rate of their class"},
         "issue_cadence": {"floor_us": round(cadence_cycles / clock_ghz / 1e3, 1),
-                          "frac": round(cadence_cycles / clock_ghz / 1e3 / us, 3), "waves_per_simd": WAVES_PER_SIMD,
+                          "frac": round(cadence_cycles / clock_ghz / 1e3 / us, 3), "waves_per_simd": waves_per_simd,
                           "cycles_per_instruction_per_wave": CADENCE,
-                          "meaning": "one wave issues <= 1 instruction per ~5 cycles; 4 resident waves per SIMD"},
+                          "meaning": f"one wave issues <= 1 instruction per ~5 cycles; {waves_per_simd} resident waves per SIMD"},
         "wave_state_shares": {k: round(c[k] / c["SQ_WAVE_CYCLES"], 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
                               if k in c and "SQ_WAVE_CYCLES" in c},
     }
@@ -124,6 +124,23 @@ def main():
         res["pyr_down"] = kernel_bounds(pmc_dir, "k_pyr_down<float", "_ZN4oflk10k_pyr_downIfLb0EEEvNS_7PyrArgsE", asm, prices)
     except Exception as e:   # counters of that kernel missing
         res["pyr_down"] = {"error": str(e)}
+    # round 4: the single-scale kernels on their own (32 pairs of 1080p, tools/profiles_r04.sh) and the streaming iteration
+    # kernel of the tolerant mode; HBM floor of a launch = algorithmic bytes / 8 TB/s beside the instruction-side floors
+    if len(sys.argv) > 4:
+        single_dir = sys.argv[4]
+        px = 32 * 1080 * 1920
+        for key, sub, match, sym, waves, bpp in (
+                ("single_tile_5x5", "tile5", "k_lkw<2, 0, true", "_ZN4oflk5k_lkwILi2ELi0ELb1EfEEvNS_6LkArgsE", 4, 16),
+                ("single_tile_7x7", "tile7", "k_lkw<3, 0, true", "_ZN4oflk5k_lkwILi3ELi0ELb1EfEEvNS_6LkArgsE", 3, 16),
+                ("single_stream_5x5", "stream5", "k_lks<0, true", "_ZN4oflk5k_lksILi0ELb1ELi0EfEEvNS_6LkArgsE", 4, 16),
+                ("iter_stream_5x5_tolerant", "tol", "k_lks<1, true, 1", "_ZN4oflk5k_lksILi1ELb1ELi1EfEEvNS_6LkArgsE", 2, 24)):
+            try:
+                r = kernel_bounds(single_dir + "/" + sub, match, sym, asm, prices, waves_per_simd=waves)
+                r["hbm_floor_us"] = round(px * bpp / 8e12 * 1e6, 1)
+                r["hbm_frac"] = round(r["hbm_floor_us"] / r["launch_us_under_pmc"], 3)
+                res[key] = r
+            except Exception as e:
+                res[key] = {"error": repr(e)}
     res["sources"] = [str(Path(pmc_dir).name), str(Path(table_path).name), "oflk_gfx950.s (make asm)", "tools/asm_cost.py (opcode classes)"]
     Path(out_path).write_text(json.dumps(res, indent=1))
     print(json.dumps(res))

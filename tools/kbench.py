@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--identical", action="store_true", help="curr = prev (exercises early exit)")
     ap.add_argument("--graph", action="store_true", help="also time one pass captured into a HIP graph")
+    ap.add_argument("--kernels", type=int, default=0, help="oflk_plan_set_kernels of the single-scale plan (0 automatic: 5x5 streams; 1: the tile kernel)")
+    ap.add_argument("--only", default="", help="'single' or 'pyramidal': run only that plan")
     ap.add_argument("--arith", type=int, default=0, help="oflk_plan_set_arithmetic mode of the pyramidal plan (0 exact, 1 contracted, 2 tolerant)")
     args = ap.parse_args()
     import torch
@@ -37,9 +39,14 @@ def main():
         ("single", _oflk.Plan(0, B, H, W, 1, args.window, 0), "single_scale"),
         ("pyramidal", _oflk.Plan(0, B, H, W, 3, args.window, 3), "pyramidal"),
     ):
+        if args.only and args.only != name:
+            plan.close()
+            continue
         call = getattr(plan, fn)
         if name == "pyramidal" and args.arith:
             plan.set_arithmetic(args.arith)
+        if name == "single" and args.kernels:
+            plan.set_kernels(args.kernels)
         for _ in range(2):
             call(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
         torch.cuda.synchronize()

@@ -24,7 +24,8 @@ def main():
 
     def run(label, B, H, W, levels, win, iters, reps, mode="f32"):
         """mode: f32 (exact path, float32 frames), u8 (exact path, uint8 frames read by the kernels),
-        fp16 (BASELINE config 5: fp16 gradients / accumulators, single-scale only)"""
+        fp16 (BASELINE config 5: fp16 gradients / accumulators, single-scale only), tolerant (opt-in OFLK_ARITH_TOLERANT),
+        tile (single-scale with the tile kernel throughout: what every round before round 4 measured)"""
         host = [synth_pair(H, W, i) for i in range(min(B, 2))]
         prev = torch.stack([torch.from_numpy(host[b % len(host)][0]) for b in range(B)]).to(dev)
         curr = torch.stack([torch.from_numpy(host[b % len(host)][1]) for b in range(B)]).to(dev)
@@ -32,6 +33,10 @@ def main():
         if mode == "u8":
             prev, curr = prev.to(torch.uint8), curr.to(torch.uint8)   # synthetic frames are integer-valued
         plan = _oflk.Plan(0, B, H, W, levels, win, iters)
+        if mode == "tolerant":
+            plan.set_arithmetic(2)
+        if mode == "tile":
+            plan.set_kernels(1)
         if mode == "fp16":
             call = lambda *a: plan.single_scale_fp16(a[0], a[1], a[2], a[3], 255.0, a[4])  # noqa: E731
         elif mode == "u8":
@@ -60,9 +65,15 @@ def main():
 
     run("configs[1]: 640x480 pair, single-scale 5x5", 1, 480, 640, 1, 5, 0, 200)
     run("configs[1] batched x256", 256, 480, 640, 1, 5, 0, 20)
+    run("configs[1] batched x256, tile kernel throughout (rounds 1-3)", 256, 480, 640, 1, 5, 0, 20, "tile")
+    run("single-scale 5x5, 1920x1080 x32", 32, 1080, 1920, 1, 5, 0, 20)
+    run("single-scale 5x5, 1920x1080 x32, tile kernel throughout", 32, 1080, 1920, 1, 5, 0, 20, "tile")
     run("configs[2]: 1920x1080 pair, 3-level pyramidal 5x5 x3", 1, 1080, 1920, 3, 5, 3, 100)
     run("configs[2] batched x32 (the batch the kernel analysis of DESIGN.md section 5 is made on)", 32, 1080, 1920, 3, 5, 3, 20)
     run("configs[2] batched x128 (bench.py workload)", 128, 1080, 1920, 3, 5, 3, 10)
+    run("configs[2] batched x32, opt-in tolerant arithmetic", 32, 1080, 1920, 3, 5, 3, 20, "tolerant")
+    run("configs[2] batched x128, opt-in tolerant arithmetic", 128, 1080, 1920, 3, 5, 3, 10, "tolerant")
+    run("configs[3] share (8 pairs of 4K), opt-in tolerant arithmetic", 8, 2160, 3840, 3, 5, 3, 10, "tolerant")
     run("configs[3]: 3840x2160, one GPU's share of 64 pairs over 8 GPUs (8 pairs)", 8, 2160, 3840, 3, 5, 3, 10)
     run("configs[1] batched x256, uint8 frames (2 B/px of frame traffic)", 256, 480, 640, 1, 5, 0, 20, "u8")
     run("configs[2] batched x32, uint8 frames", 32, 1080, 1920, 3, 5, 3, 20, "u8")
