@@ -184,6 +184,13 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
 
     const LeanGeom lg = lean_geom(H, W);
     const double gxd0 = (double)c0, gxd1 = (double)c1;
+    // ITER: flow += d (lucas_kanade_pyramidal.py:209-210) needs the flow of an output row again, four rows after its warp
+    // coordinates were formed from it.  Re-reading it from memory cost 8 B/px of fabric traffic (measured: the launch
+    // fetched 1.58x its algorithmic reads); a wave keeps its last eight flow rows in LDS instead -- 16 bytes per lane and
+    // row, written when the row's coordinates are formed, read back by the same lane: no barrier, no bank conflict.
+    constexpr int FRING = 8;
+    __shared__ float4 s_flow[MODE == MODE_ITER ? WPB * FRING * 64 : 1];
+    float4 *const ring = s_flow + (MODE == MODE_ITER ? (threadIdx.x >> 6) * (FRING * 64) + lane : 0);
 
     // ---- pipeline state ------------------------------------------------------------------------------------
     // coalesced loads run LD rows ahead of the arithmetic (a multiple of 3, the period of the other rings: the row loop is
@@ -213,7 +220,6 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     double dsu = 0.0, dsv = 0.0;          // ... of the segment
     unsigned inexact = 0u;                // SINGLE: a window of this lane's neighbourhood may differ from NumPy's (since the last flush)
     int hold = 0;                         // SINGLE, float32 frames: iterations a non-integral pixel keeps `inexact` set
-    float4 pf_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // ITER: the flow of the next output row
 
     const int r0 = ys - R;                // first average row
     const int n_it = (ye - ys) + 2 * R;   // average rows r0 .. ye + R - 1
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
             const double yd = uint_to_f64_bits(gy);   // scalar ALU: the row is wave-uniform
             float4 f = Fr[slot];
             fix_flow2(f);
+            ring[(r & (FRING - 1)) * 64] = f;   // (rows above the frame repeat row 0: harmless, they are never output rows)
             // int64 + float32 -> float64, as the reference (lucas_kanade_pyramidal.py:88-95)
             gt[0] = lean_frac_at(lg, yd + (double)f.y, gxd0 + (double)f.x);
             gt[1] = lean_frac_at(lg, yd + (double)f.w, gxd1 + (double)f.z);
@@ -296,13 +303,12 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
             const bool o_live = o >= ys && o < ye;             // uniform: the pipeline is full and the row is the segment's
             __builtin_amdgcn_sched_barrier(0);                 // the waits above come before the issues below
             // Vector-memory results return in issue order, so a wait for one load is a wait for every load issued before
-            // it: the loads of an iteration go out oldest-needed first -- the flow of the NEXT output row (flow += d,
-            // lucas_kanade_pyramidal.py:209-210, needs it again: an L2 hit), the gathers of the next row, the coalesced
+            // it: the loads of an iteration go out oldest-needed first -- the gathers of the next row, then the coalesced
             // loads three rows ahead -- and every wait leaves the younger ones in flight.
-            float4 pf = pf_next;   // (lane_out lanes of a VEC launch lie inside the frame: no fix-up needed)
+            float4 pf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if constexpr (MODE == MODE_ITER) {
                 if constexpr (!(OFLK_LKS_ABL & 2))
-                    if (o + 1 >= ys) pf_next = load_flow2(fin, row_e(o + 1));
+                    if (o_live) pf = ring[(o & (FRING - 1)) * 64];   // written four iterations ago by this lane
                 issue_gathers((jl + 1) % LD, r + 1);          // used by the next row, after this row's arithmetic
             }
             issue_loads(jl, r + LD);
