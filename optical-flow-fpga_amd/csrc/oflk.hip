@@ -424,7 +424,16 @@ int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int 
         }                                                                                                     \
     } while (0)
     if constexpr (MODE == MODE_ITER) {
-        if (warp == WARP_LERP64) OFLK_LAUNCH_LKS(WARP_LERP64);
+        if (a.up_src != nullptr) {
+            // first iteration of a level with the flow upsampling fused in (tolerant mode)
+            if (u8) {
+                if (vec) hipLaunchKernelGGL((k_lks<MODE_ITER, true, WARP_LERP64, unsigned char, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((k_lks<MODE_ITER, false, WARP_LERP64, unsigned char, true>), grid, block, 0, s, a);
+            } else {
+                if (vec) hipLaunchKernelGGL((k_lks<MODE_ITER, true, WARP_LERP64, float, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((k_lks<MODE_ITER, false, WARP_LERP64, float, true>), grid, block, 0, s, a);
+            }
+        } else if (warp == WARP_LERP64) OFLK_LAUNCH_LKS(WARP_LERP64);
         else OFLK_LAUNCH_LKS(WARP_SCIPY);
     } else {
         OFLK_LAUNCH_LKS(WARP_SCIPY);
@@ -918,7 +927,11 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
     for (int l = 0; l < L; l++) {
         const int h = p->dims[2 * l], w = p->dims[2 * l + 1];
         const size_t n = (size_t)h * w;
-        if (l > 0) {
+        // tolerant mode: the two finest levels take the streaming kernel (order-free window sums, fused-lerp warp), and the flow
+        // upsampling into such a level is fused into its first iteration
+        const bool stream = p->arith == OFLK_ARITH_TOLERANT && p->hw == 2 && l >= L - 2 && h > 4 && w > 4;
+        const bool fuse_up = stream && l > 0 && K >= 1 && p->dims[2 * (l - 1)] >= 2 && p->dims[2 * (l - 1) + 1] >= 2;
+        if (l > 0 && !fuse_up) {
             // upsample_flow (:195-197) from whichever slot holds level l-1's result
             const int hc = p->dims[2 * (l - 1)], wc = p->dims[2 * (l - 1) + 1];
             ResampleArgs r{};
@@ -954,8 +967,19 @@ int plan_pyramidal(oflk_plan *p, const void *d_prev_in, const void *d_curr_in, b
             a.conv_thr = conv_threshold((double)n);
             a.level = l; a.iter = k; a.L = L; a.K = p->Kc();
             a.H = h; a.W = w;
-            // tolerant mode: the two finest levels take the streaming kernel (order-free window sums, fused-lerp warp)
-            const bool stream = p->arith == OFLK_ARITH_TOLERANT && p->hw == 2 && l >= L - 2 && h > 4 && w > 4;
+            if (fuse_up && k == 0) {
+                const int hc = p->dims[2 * (l - 1)], wc = p->dims[2 * (l - 1) + 1];
+                a.up_src = p->fl(l - 1, 0);
+                a.up_slot_stride = (size_t)B * p->npix(l - 1);
+                a.up_level = l - 1;
+                a.up_iters = K;
+                a.up_thr = conv_threshold((double)p->npix(l - 1));
+                a.Hc = hc; a.Wc = wc;
+                a.up_ly = make_linspace(hc, h);
+                a.up_lx = make_linspace(wc, w);
+                a.up_sx = (float)((double)w / (double)wc);   // scale_x (:123, :135)
+                a.up_sy = (float)((double)h / (double)hc);   // scale_y (:122, :136)
+            }
             if (stream) rc = launch_lks<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, a, B, u8 && l == L - 1, WARP_LERP64);
             else rc = launch_lk<MODE_ITER>(p, s, l == L - 1 ? KC_LK_ITER_FINEST : KC_LK_ITER, p->hw, a, B, u8 && l == L - 1);
             if (rc) return rc;

@@ -428,6 +428,16 @@ struct LkArgs {
     // block to finish resets [0] and [1]: the buffer is all zero between calls.  nullptr: no list.
     unsigned *redo;
     int redo_pass;
+    // streaming kernel, first iteration of a level in the tolerant mode (k_lks<.., UPS = true>): the level's initial flow is
+    // the coarser level's final flow upsampled on the fly (upsample_flow, lucas_kanade_pyramidal.py:100-138, in the
+    // fused-lerp form) instead of planes written by k_upsample and read back: 16 B/px of traffic and a launch less
+    const float2 *up_src;        // the coarser level's two flow slots [2][B][Hc][Wc], interleaved {u, v}
+    size_t up_slot_stride;       // elements between the slots
+    int up_level, up_iters;      // the coarser level's index; iterations launched per level (lk_level_state)
+    unsigned long long up_thr;   // its convergence threshold
+    int Hc, Wc;
+    Linspace up_ly, up_lx;       // np.linspace(0, Hc-1, H), np.linspace(0, Wc-1, W)
+    float up_sx, up_sy;          // float32(W / Wc), float32(H / Hc)
 #ifdef OFLK_STAMPS
     unsigned *stamps;   // diagnostic build only: [block][wave][16] cycle sums per code section
 #endif

@@ -89,10 +89,13 @@ constexpr float kLksExactBound = 65536.0f;
 #else
 #define OFLK_LKS_ATTR
 #endif
-template <int MODE, bool VEC, int WARPV, class PIX = float>
+struct __attribute__((packed, aligned(8))) Flow2 { float u0, v0, u1, v1; };   // two adjacent {u, v} cells at an 8-byte aligned address
+
+template <int MODE, bool VEC, int WARPV, class PIX = float, bool UPS = false>
 __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
 {
     static_assert(MODE == MODE_SINGLE || MODE == MODE_ITER, "gradient planes take the tile kernel");
+    static_assert(!UPS || MODE == MODE_ITER, "the fused flow upsampling belongs to an iteration");
     constexpr int HW = 2, R = HW + 1, HL = 2, OUTW = kLksOutW, WPB = 4;
     constexpr int SHR = 0x138, SHL = 0x130;   // DPP wave_shr:1 / wave_shl:1
     const int lane = threadIdx.x & 63;
@@ -188,6 +191,22 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     // coordinates were formed from it.  Re-reading it from memory cost 8 B/px of fabric traffic (measured: the launch
     // fetched 1.58x its algorithmic reads); a wave keeps its last eight flow rows in LDS instead -- 16 bytes per lane and
     // row, written when the row's coordinates are formed, read back by the same lane: no barrier, no bank conflict.
+    // UPS: the x side of the upsampling is fixed per lane -- coarse cell and fraction of the lane's two columns (the cells
+    // are the same or adjacent: a fine pixel is less than a coarse one wide) -- the y side is uniform per row
+    const float2 *__restrict__ csrc = nullptr;
+    int xb = 0, xd = 0;            // coarse column of the low fine column; 0 / 1: the high column's cell is the next one
+    double urx0 = 0.0, urx1 = 0.0;
+    if constexpr (UPS) {
+        const int up_sel = lk_level_state(a.acc, b, a.up_level, a.up_iters, a.L, a.K, a.up_thr).executed & 1;
+        csrc = a.up_src + (size_t)up_sel * a.up_slot_stride + (size_t)b * ((size_t)a.Hc * (size_t)a.Wc);
+        const double Wc2 = (double)max(a.Wc - 2, 0);
+        const double x0f = linspace_at(a.up_lx, c0), x1f = linspace_at(a.up_lx, c1);
+        const double f0 = fmin(floor(x0f), Wc2), f1 = fmin(floor(x1f), Wc2);
+        urx0 = x0f - f0;
+        urx1 = x1f - f1;
+        xb = (int)f0;
+        xd = (int)f1 - xb;
+    }
     constexpr int FRING = 8;
     __shared__ float4 s_flow[MODE == MODE_ITER ? WPB * FRING * 64 : 1];
     float4 *const ring = s_flow + (MODE == MODE_ITER ? (threadIdx.x >> 6) * (FRING * 64) + lane : 0);
@@ -202,6 +221,8 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     float2 Qr[LD];                        // SINGLE: curr rows
     float4 Fr[LD];                        // ITER: flow rows
     float Cr[LD];                         // ITER: prefetch of `curr` (see issue_loads)
+    Flow2 Ua[UPS ? LD : 1][2];            // UPS: coarse cells xb, xb+1 of the two tap rows
+    float2 Ub[UPS ? LD : 1][2];           // UPS: coarse cell xb+2
     LeanFrac gt[2];                       // ITER: the gathers in flight (row r + 1)
     PairF g0[2], g1[2];
     // frame-average rows {lo, hi, left neighbour of lo, right neighbour of hi}, ring of three
@@ -228,7 +249,19 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     auto issue_loads = [&](int slot, int r) {
         const unsigned rowe = row_e(r);
         Pr[slot] = load_pix2(prev, rowe);
-        if constexpr (MODE == MODE_ITER) {
+        if constexpr (UPS) {
+            // the taps of the flow upsampling for fine row r: coarse rows y0, y0 + 1 (floor capped at Hc - 2: a sample on the last
+            // row is the cell before it with fraction 1), coarse cells xb .. xb + 2 (the last one clamped into the row)
+            const double yf = linspace_at(a.up_ly, min(max(r, 0), Hm1));
+            const int y0c = __builtin_amdgcn_readfirstlane((int)fmin(floor(yf), (double)max(a.Hc - 2, 0)));   // uniform, but formed on the vector ALU
+            const float2 *row0 = csrc + (size_t)y0c * (size_t)a.Wc, *row1 = csrc + (size_t)min(y0c + 1, a.Hc - 1) * (size_t)a.Wc;
+            const unsigned ob = (unsigned)xb * 8u, oc = (unsigned)min(xb + 2, a.Wc - 1) * 8u;
+            Ua[slot][0] = ld_off<Flow2>(row0, ob);
+            Ub[slot][0] = ld_off<float2>(row0, oc);
+            Ua[slot][1] = ld_off<Flow2>(row1, ob);
+            Ub[slot][1] = ld_off<float2>(row1, oc);
+            Cr[slot] = ld_pix<PIX>(scalar_ptr(curr + row_e(r + OFLK_LKS_PFROWS)), (unsigned)c0);
+        } else if constexpr (MODE == MODE_ITER) {
             Fr[slot] = load_flow2(fin, rowe);
             // the warp's gathers two rows later find `curr` in the L2 instead of paying the HBM's latency inside the row loop:
             // a coalesced read of the same row brings its lines in (flows of a few pixels stay inside them)
@@ -242,8 +275,28 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
         if constexpr (MODE == MODE_ITER) {
             const int gy = min(max(r, 0), Hm1);
             const double yd = uint_to_f64_bits(gy);   // scalar ALU: the row is wave-uniform
-            float4 f = Fr[slot];
-            fix_flow2(f);
+            float4 f;
+            if constexpr (UPS) {
+                // upsample_flow at the lane's two pixels of row r: three fused lerps per plane in fp64, float32, then the
+                // float32 multiply by float32(scale) of :135-136
+                const double yf = linspace_at(a.up_ly, gy);
+                const double ury = yf - fmin(floor(yf), (double)max(a.Hc - 2, 0));
+                const Flow2 t0 = Ua[slot][0], t1 = Ua[slot][1];
+                const float2 e0 = Ub[slot][0], e1 = Ub[slot][1];
+                auto lerp = [&](float p00, float p01, float p10, float p11, double rx) {
+                    const double A = (double)p00, B = (double)p01, C = (double)p10, D = (double)p11;
+                    const double top = __builtin_fma(rx, B - A, A), bot = __builtin_fma(rx, D - C, C);
+                    return (float)__builtin_fma(ury, bot - top, top);
+                };
+                const bool nx = xd != 0;   // the high column's cell is the next one
+                f.x = lerp(t0.u0, t0.u1, t1.u0, t1.u1, urx0) * a.up_sx;
+                f.y = lerp(t0.v0, t0.v1, t1.v0, t1.v1, urx0) * a.up_sy;
+                f.z = lerp(nx ? t0.u1 : t0.u0, nx ? e0.x : t0.u1, nx ? t1.u1 : t1.u0, nx ? e1.x : t1.u1, urx1) * a.up_sx;
+                f.w = lerp(nx ? t0.v1 : t0.v0, nx ? e0.y : t0.v1, nx ? t1.v1 : t1.v0, nx ? e1.y : t1.v1, urx1) * a.up_sy;
+            } else {
+                f = Fr[slot];
+                fix_flow2(f);
+            }
             ring[(r & (FRING - 1)) * 64] = f;   // (rows above the frame repeat row 0: harmless, they are never output rows)
             // int64 + float32 -> float64, as the reference (lucas_kanade_pyramidal.py:88-95)
             gt[0] = lean_frac_at(lg, yd + (double)f.y, gxd0 + (double)f.x);

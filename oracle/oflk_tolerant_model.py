@@ -49,16 +49,22 @@ class Spec:
         return s
 
 
-def tolerant_spec(levels: int = 3, iters: int = 3, up: str = "exact") -> Spec:
+def tolerant_spec(levels: int = 3, iters: int = 3, shape=None) -> Spec:
     """what OFLK_ARITH_TOLERANT computes (keep in step with plan_pyramidal in csrc/oflk.hip and DESIGN.md section 2): the
     pyramid with fused multiply-adds; on the two finest levels the streaming kernel -- fused-lerp fp64 warp, window sums
-    vertical first then horizontal; coarser levels exact"""
+    vertical first then horizontal -- with the flow upsampling INTO such a level in the fused-lerp form too (it is fused
+    into the level's first iteration); coarser levels exact.  shape = (H, W): levels too small for the streaming kernel
+    (5 pixels or fewer along an axis) run exactly, as in the library."""
     s = Spec(levels, iters)
     s.pyr[:] = PYR["contracted"]
-    s.up[:] = UP[up]
+    dims = O.pyramid_dims(int(shape[0]), int(shape[1]), levels, 0.5) if shape is not None else None
     for l in range(max(levels - 2, 0), levels):
+        if dims is not None and (dims[l][0] <= 4 or dims[l][1] <= 4):
+            continue
         s.warp[l, :] = WARP["lerp64"]
         s.sums[l, :] = SUMS["sep_vfirst"]
+        if l > 0 and iters >= 1 and (dims is None or (dims[l - 1][0] >= 2 and dims[l - 1][1] >= 2)):
+            s.up[l] = UP["lerp64"]
     return s
 
 

@@ -48,7 +48,7 @@ def _run(plan, p, c, u8=False):
 def _model(p, c, L, K):
     import oflk_tolerant_model as M
 
-    return M.pyramidal(p.astype(np.float32), c.astype(np.float32), M.tolerant_spec(L, K), 5)
+    return M.pyramidal(p.astype(np.float32), c.astype(np.float32), M.tolerant_spec(L, K, p.shape), 5)
 
 
 def _pair(rng, H, W, kind):
