@@ -404,6 +404,8 @@ int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int 
     const double rounds = (double)(strips * segs) / (double)slots;
     if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
     else segs = std::max(segs, std::min(slots / std::max<long>(strips, 1), std::max<long>(1, a.H / 40)));   // fill the one round, >= 40 rows each
+    // a launch that cannot fill the slots even so (a single pair in the tolerant mode) trades rows per segment for parallel waves
+    if (strips * segs < slots / 2) segs = std::max(segs, std::min(slots / 2 / std::max<long>(strips, 1), std::max<long>(1, a.H / 12)));
     segs = std::min<long>(segs, std::max<long>(1, a.H / 8));
     a.Hs = (int)(((long)a.H + segs - 1) / segs);
     a.segs = (a.H + a.Hs - 1) / a.Hs;
@@ -756,7 +758,12 @@ int plan_single_scale(oflk_plan *p, const void *d_prev, const void *d_curr, bool
     a.curr = static_cast<const float *>(d_curr);
     a.ou = d_u; a.ov = d_v;
     a.H = p->H; a.W = p->W;
-    if (p->hw == 2 && p->H > 4 && p->W > 4 && p->kernels == OFLK_KERNELS_AUTO) {
+    // The streaming kernel walks rows one after the other inside a wave: a launch too small to fill the chip's wave slots with
+    // segments of ~40 rows is latency-bound there (one 640x480 pair: 37 us against the tile kernel's 6), so small launches
+    // keep the tile kernel -- both are exact, the choice is speed only.
+    const long stream_waves = ((long)p->W + kLksOutW - 1) / kLksOutW * p->B * std::max(1, p->H / 40);
+    if (p->hw == 2 && p->H > 4 && p->W > 4 &&
+        ((p->kernels == OFLK_KERNELS_AUTO && stream_waves >= 2048) || p->kernels == OFLK_KERNELS_STREAM)) {
         // 5x5 window: the streaming kernel, whose order-free sums are NumPy's wherever the frames are integers in [0, 255]
         // and a window's Sxx, Syy stay below 2^16 (proof at kLksExactBound); it flags the tiles where that is in doubt and
         // the tile kernel redoes exactly those in NumPy's order.  Results are the reference's either way.
@@ -1276,8 +1283,8 @@ OFLK_API int oflk_multi_rehearsal(int workers)
 OFLK_API int oflk_plan_set_kernels(oflk_plan *p, int choice)
 {
     if (!p) return fail(OFLK_ERR_INVALID, "NULL plan");
-    if (choice != OFLK_KERNELS_AUTO && choice != OFLK_KERNELS_TILE)
-        return fail(OFLK_ERR_INVALID, "kernel choice must be OFLK_KERNELS_AUTO (0) or OFLK_KERNELS_TILE (1), got %d", choice);
+    if (choice != OFLK_KERNELS_AUTO && choice != OFLK_KERNELS_TILE && choice != OFLK_KERNELS_STREAM)
+        return fail(OFLK_ERR_INVALID, "kernel choice must be OFLK_KERNELS_AUTO (0), OFLK_KERNELS_TILE (1) or OFLK_KERNELS_STREAM (2), got %d", choice);
     p->kernels = choice;
     return OFLK_OK;
 }

@@ -234,7 +234,8 @@ class Plan:
         check(lib().oflk_plan_set_arithmetic(self._h, int(mode)))
 
     def set_kernels(self, choice: int) -> None:
-        """0: automatic (5x5 single-scale streams, doubtful tiles redone in NumPy's order); 1: the tile kernel throughout"""
+        """0: automatic (5x5 single-scale streams when the launch is large enough; doubtful tiles redone in NumPy's order);
+        1: the tile kernel throughout; 2: the streaming kernel whenever the window is 5x5"""
         check(lib().oflk_plan_set_kernels(self._h, int(choice)))
 
     def set_profiling(self, enabled) -> None:

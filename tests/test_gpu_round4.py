@@ -193,8 +193,9 @@ def _frames(kind, rng, H, W):
 @pytest.mark.parametrize("shape", [(480, 640), (241, 323), (97, 130), (24, 64), (25, 121), (1080, 1920)])
 @pytest.mark.parametrize("kind", ["synth", "noise", "edges", "fractional", "speckled"])
 def test_single_scale_streaming_path_is_exact(oracle, shape, kind):
-    """oflk_plan_single_scale, 5x5, automatic kernel choice == the oracle value for value, for every kind of frame: the
-    doubtful tiles (bound exceeded, non-integral or out-of-range pixels) are redone in NumPy's order inside the call"""
+    """oflk_plan_single_scale, 5x5, through the streaming kernel == the oracle value for value, for every kind of frame: the
+    doubtful tiles (bound exceeded, non-integral or out-of-range pixels) are redone in NumPy's order inside the call; the tile
+    kernel and the automatic choice give the same"""
     import _oflk
 
     H, W = shape
@@ -203,7 +204,7 @@ def test_single_scale_streaming_path_is_exact(oracle, shape, kind):
     ou, ov = oracle.lucas_kanade_single_scale(p, c, 5)
     plan = _oflk.Plan(0, 2, H, W, 1, 5, 0)
     pp, cc = np.stack([p, c]), np.stack([c, p])        # two pairs per call (the second one reversed)
-    for choice in (0, 1, 0):
+    for choice in (2, 1, 0, 2):   # streaming kernel forced, tile kernel, automatic (by launch size), streaming again
         plan.set_kernels(choice)
         u, v = _single(plan, pp, cc)
         assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), (shape, kind, choice)
@@ -228,6 +229,7 @@ def test_single_scale_bound_of_the_exactness_argument(oracle):
         b = np.roll(a, (1, 1), axis=(0, 1))
         ou, ov = oracle.lucas_kanade_single_scale(a, b, 5)
         plan = _oflk.Plan(0, 1, H, W, 1, 5, 0)
+        plan.set_kernels(2)
         u, v = _single(plan, a[None], b[None])
         assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), h
         plan.close()

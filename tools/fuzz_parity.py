@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run: HIP path vs the CPU oracle on random shapes, parameters and data
 (development tool, run on the GPU box; the committed test-suite holds the fixed cases).
-Usage: python3 tools/fuzz_parity.py [cases] [seed] | batch [cases] [seed] | rtl [cases] [seed]"""
+Usage: python3 tools/fuzz_parity.py [cases] [seed] | batch [cases] [seed] | rtl [cases] [seed] | tol [cases] [seed]"""
 import os
 import sys
 from pathlib import Path
@@ -102,7 +102,69 @@ def rtl_main(cases, seed):
     print(f"done: {cases} rtl cases, {bad} mismatches")
 
 
+def tol_main(cases, seed):
+    """opt-in tolerant arithmetic: a plan in OFLK_ARITH_TOLERANT against its CPU statement (oracle/oflk_tolerant_model.c),
+    bit for bit -- flows and iteration counts -- on random shapes, levels, iteration counts, batch sizes, float32 and uint8"""
+    import torch
+
+    import _oflk
+    import oflk_tolerant_model as M
+
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    bad = 0
+    for i in range(cases):
+        H, W = int(rng.integers(6, 420)), int(rng.integers(6, 560))
+        L, K = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        while L > 1 and (int(H * 0.5 ** (L - 1)) < 1 or int(W * 0.5 ** (L - 1)) < 1):
+            L -= 1
+        B = int(rng.integers(1, 4))
+        kind = int(rng.integers(0, 3))
+        prs = []
+        for _ in range(B):
+            if kind == 0:
+                a = rng.integers(0, 256, (H, W)).astype(np.float32)
+                b = np.clip(np.roll(a, (int(rng.integers(-2, 3)), int(rng.integers(-3, 4))), (0, 1)) + rng.integers(-5, 6, (H, W)), 0, 255).astype(np.float32)
+            elif kind == 1:
+                yy, xx = np.mgrid[0:H, 0:W]
+                a = np.round(128 + 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + rng.normal(0, 4, (H, W))).clip(0, 255).astype(np.float32)
+                b = np.round(128 + 60 * np.sin((xx - 1.7) / 7.0) * np.cos((yy + 0.6) / 5.0) + rng.normal(0, 4, (H, W))).clip(0, 255).astype(np.float32)
+            else:
+                a = (rng.random((H, W)) * 255).astype(np.float32)
+                b = (np.roll(a, 1, 1) * np.float32(0.98) + rng.normal(0, 1, (H, W))).astype(np.float32)
+            prs.append((a, b))
+        prev, curr = np.stack([p for p, _ in prs]), np.stack([c for _, c in prs])
+        plan = _oflk.Plan(0, B, H, W, L, 5, K)
+        plan.set_arithmetic(2)
+        tp, tc = torch.from_numpy(prev).to(dev), torch.from_numpy(curr).to(dev)
+        u, v = torch.empty_like(tp), torch.empty_like(tp)
+        plan.pyramidal(tp.data_ptr(), tc.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+        _, runs = plan.read_log(st)
+        torch.cuda.synchronize()
+        hu, hv = u.cpu().numpy(), v.cpu().numpy()
+        ok = True
+        for b_, (a, b) in enumerate(prs):
+            mu, mv, _, mruns = M.pyramidal(a, b, M.tolerant_spec(L, K, (H, W)), 5)
+            ok &= same(hu[b_], mu) and same(hv[b_], mv) and list(runs[b_]) == list(mruns)
+        if kind < 2:
+            t8p, t8c = tp.to(torch.uint8), tc.to(torch.uint8)
+            plan.pyramidal_u8(t8p.data_ptr(), t8c.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+            torch.cuda.synchronize()
+            ok &= same(u.cpu().numpy(), hu) and same(v.cpu().numpy(), hv)
+        plan.close()
+        if not ok:
+            bad += 1
+            print(f"MISMATCH tol case {i}: B={B} H={H} W={W} L={L} K={K} kind={kind}", flush=True)
+        if i % 50 == 49:
+            print(f"{i + 1} tol cases, {bad} mismatches", flush=True)
+    print(f"done: {cases} tol cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "tol":
+        return tol_main(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] == "rtl":
         return rtl_main(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] == "batch":
