@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run: HIP path vs the CPU oracle on random shapes, parameters and data
 (development tool, run on the GPU box; the committed test-suite holds the fixed cases).
-Usage: python3 tools/fuzz_parity.py [cases] [seed] | batch [cases] [seed] | rtl [cases] [seed] | tol [cases] [seed]"""
+Usage: python3 tools/fuzz_parity.py [cases] [seed] | batch [cases] [seed] | rtl [cases] [seed] | tol [cases] [seed] | stream [cases] [seed]"""
 import os
 import sys
 from pathlib import Path
@@ -162,7 +162,77 @@ def tol_main(cases, seed):
     sys.exit(1 if bad else 0)
 
 
+def stream_main(cases, seed):
+    """single-scale 5x5 with the streaming kernel FORCED (oflk_plan_set_kernels(OFLK_KERNELS_STREAM)): exact on 8-bit frames,
+    doubtful tiles redone by the tile kernel -- against the oracle, value for value, on every kind of frame"""
+    import torch
+
+    import _oflk
+
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    bad = 0
+    for i in range(cases):
+        H, W = int(rng.integers(5, 600)), int(rng.integers(5, 800))
+        B = int(rng.integers(1, 4))
+        kind = int(rng.integers(0, 5))
+        prs = []
+        for _ in range(B):
+            if kind == 0:      # 8-bit noise
+                a = rng.integers(0, 256, (H, W)).astype(np.float32)
+                b = np.roll(a, int(rng.integers(-3, 4)), axis=1)
+            elif kind == 1:    # 8-bit texture with hard 0 / 255 patches (windows over the bound)
+                yy, xx = np.mgrid[0:H, 0:W]
+                a = np.round(128 + 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + rng.normal(0, 4, (H, W))).clip(0, 255)
+                for _ in range(4):
+                    y, x = int(rng.integers(0, H)), int(rng.integers(0, W))
+                    a[y:y + 9, x:x + 13] = 255.0 * ((np.add.outer(np.arange(min(9, H - y)), np.arange(min(13, W - x))) // 2) % 2)
+                a = a.astype(np.float32)
+                b = np.roll(a, (1, 2), (0, 1))
+            elif kind == 2:    # not integers
+                a = (rng.random((H, W)) * 255).astype(np.float32)
+                b = (np.roll(a, 1, 1) * np.float32(0.99)).astype(np.float32)
+            elif kind == 3:    # signed, wide dynamic range
+                a = (rng.normal(0, 1, (H, W)) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+                b = (a + rng.normal(0, 0.1, (H, W)) * 10.0 ** rng.integers(-3, 3)).astype(np.float32)
+            else:              # 8-bit with a few stray pixels (fractional, negative, above 255)
+                a = rng.integers(0, 256, (H, W)).astype(np.float32)
+                b = np.roll(a, (1, -1), (0, 1)).copy()
+                for _ in range(3):
+                    a[int(rng.integers(0, H)), int(rng.integers(0, W))] = np.float32(rng.choice([0.5, -3.0, 255.25, 1000.0]))
+                    b[int(rng.integers(0, H)), int(rng.integers(0, W))] = np.float32(rng.choice([17.75, -0.5, 256.0]))
+            prs.append((a, b))
+        prev, curr = np.stack([p for p, _ in prs]), np.stack([c for _, c in prs])
+        plan = _oflk.Plan(0, B, H, W, 1, 5, 0)
+        plan.set_kernels(2)
+        tp, tc = torch.from_numpy(prev).to(dev), torch.from_numpy(curr).to(dev)
+        u, v = torch.empty_like(tp), torch.empty_like(tp)
+        plan.single_scale(tp.data_ptr(), tc.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+        torch.cuda.synchronize()
+        hu, hv = u.cpu().numpy(), v.cpu().numpy()
+        ok = True
+        for b_, (a, b) in enumerate(prs):
+            ou, ov = O.lucas_kanade_single_scale(a, b, 5)
+            ok &= same(hu[b_], ou) and same(hv[b_], ov)
+        if kind in (0, 1):
+            t8p, t8c = tp.to(torch.uint8), tc.to(torch.uint8)   # (kept alive until the kernels have run)
+            plan.single_scale_u8(t8p.data_ptr(), t8c.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+            torch.cuda.synchronize()
+            ok &= same(u.cpu().numpy(), hu) and same(v.cpu().numpy(), hv)
+        plan.close()
+        if not ok:
+            bad += 1
+            print(f"MISMATCH stream case {i}: B={B} H={H} W={W} kind={kind}", flush=True)
+        if i % 50 == 49:
+            print(f"{i + 1} stream cases, {bad} mismatches", flush=True)
+    print(f"done: {cases} stream cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "stream":
+        return stream_main(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] == "tol":
         return tol_main(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] == "rtl":
