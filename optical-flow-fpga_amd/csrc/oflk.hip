@@ -392,6 +392,9 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
 // order (the tolerant mode's fine levels; single-scale on integer-valued frames, where any order is exact).  One wave
 // per (strip of 120 output columns, segment of Hs rows); segments are sized so that the launch is a whole number of
 // rounds of the chip's wave slots at the kernel's occupancy, ~64 rows or more each (a segment pays 6 extra rows).
+#ifndef OFLK_LKS_SEG_ROWS
+#define OFLK_LKS_SEG_ROWS 128
+#endif
 template <int MODE>
 int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int B, bool u8, int warp)
 {
@@ -400,7 +403,7 @@ int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int 
     Prof pr(plan, s, cls);
     const long strips = ((long)a.W + kLksOutW - 1) / kLksOutW * B;
     const long slots = 256 * 4 * (MODE == MODE_SINGLE ? 4 : OFLK_LKS_WAVES);   // wave slots of the chip at the kernel's occupancy (SINGLE: ~100 VGPRs)
-    long segs = ((long)a.H + 63) / 64;
+    long segs = ((long)a.H + OFLK_LKS_SEG_ROWS - 1) / OFLK_LKS_SEG_ROWS;   // a segment pays 6 extra rows: ~128 rows each when the launch has rounds to spare
     const double rounds = (double)(strips * segs) / (double)slots;
     if (rounds > 0.75) segs = std::max<long>(1, (long)std::ceil(rounds - 0.25) * slots / strips);
     else segs = std::max(segs, std::min(slots / std::max<long>(strips, 1), std::max<long>(1, a.H / 40)));   // fill the one round, >= 40 rows each
