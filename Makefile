@@ -14,6 +14,6 @@ bench:            ## one JSON line (128 pairs of 1080p per step, 3-level pyramid
 	$(PY) bench.py
 
 profiles:         ## regenerate profiles/<tag>_* on the GPU box
-	bash tools/refresh_profiles.sh r03
+	bash tools/profiles_r04.sh
 
 .PHONY: build test test-gpu bench profiles
