@@ -662,7 +662,7 @@ void plan_free(oflk_plan *p)
 // =============================================================================
 // library
 // =============================================================================
-OFLK_API const char *oflk_version(void) { return "oflk 0.3.0 (gfx950)"; }
+OFLK_API const char *oflk_version(void) { return "oflk 0.4.0 (gfx950)"; }
 
 OFLK_API int oflk_device_count(void)
 {
