@@ -347,3 +347,66 @@ def test_contracted_mode_against_the_reference_dense_flows(golden_dir):
     for i, n in enumerate(names):
         assert list(runs[i]) == list(dense[f"{n}__iters"]), n
         assert _epe(u[i], v[i], dense[f"{n}__u"], dense[f"{n}__v"]) <= TOL, n
+
+
+def test_tolerant_mode_keeps_the_exit_decision_band_and_its_exact_redo(oracle):
+    """In the tolerant mode a level's mean |d| differs from the reference's by the mode's arithmetic AND by the summation
+    order, so a decision taken within the band around 0.01 is flagged exactly as in the exact mode, and
+    oflk_plan_resolve_uncertain redoes the pair EXACTLY (its own exact pyramid): the redone pair equals the oracle -- inside
+    any tolerance -- while pairs far from the threshold stay the tolerant model's.  Frames curr_t = prev + t * (shifted - prev),
+    t bisected on the device's own first mean of the coarsest level until it sits 2e-5 (relative) above the threshold."""
+    import torch
+
+    import _oflk
+    import oflk_tolerant_model as M
+    from oflk_synth import synth_pair
+
+    H, W, L, K = 96, 128, 2, 3
+    prev, shifted = synth_pair(H, W, 0, dx=0.75, dy=-0.5)
+    delta = (shifted - prev).astype(np.float64)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    d_prev = torch.from_numpy(prev[None]).to(dev)
+    u, v = torch.empty_like(d_prev), torch.empty_like(d_prev)
+    plan = _oflk.Plan(0, 1, H, W, L, 5, K)
+    plan.set_arithmetic(2)
+
+    def run(t):
+        c = (prev + t * delta).astype(np.float32)
+        d_curr = torch.from_numpy(c[None]).to(dev)
+        plan.pyramidal(d_prev.data_ptr(), d_curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+        log, runs = plan.read_log(st)
+        torch.cuda.synchronize()
+        return c, d_curr, float(max(log[0, 0, 0])), list(runs[0])
+
+    thr = float(np.float32(0.01))
+    target = thr * (1.0 + 2e-5)
+    lo, hi = 0.0, 1.0
+    assert run(lo)[2] < target < run(hi)[2]
+    got = None
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        c, d_curr, m, runs = run(mid)
+        if 0.5e-5 < m / thr - 1.0 < 4e-5:
+            got = (c, d_curr, m, runs)
+            break
+        if m < target:
+            lo = mid
+        else:
+            hi = mid
+    assert got is not None, "the bisection never landed inside the band: the construction is broken"
+    c, d_curr, m, runs = got
+    flags = plan.read_uncertain(st)
+    assert flags.astype(bool).any(), f"a first mean {m / thr - 1.0:.2e} above the threshold was not flagged"
+    n = plan.resolve_uncertain(d_prev.data_ptr(), d_curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)
+    assert n == 1
+    ou, ov, _, oruns = oracle.lucas_kanade_pyramidal_ex(prev, c, L, 5, K)
+    _, runs2 = plan.read_log(st)
+    assert list(runs2[0]) == list(oruns)
+    assert np.array_equal(u.cpu().numpy()[0], ou) and np.array_equal(v.cpu().numpy()[0], ov)   # exact, not merely close
+    # far from the threshold: no flag, the tolerant model's flow
+    c, d_curr, m, runs = run(1.0)
+    assert not plan.read_uncertain(st).astype(bool).any()
+    mu, mv, _, mruns = M.pyramidal(prev, c, M.tolerant_spec(L, K, (H, W)), 5)
+    assert list(runs) == list(mruns) and np.array_equal(u.cpu().numpy()[0], mu) and np.array_equal(v.cpu().numpy()[0], mv)
+    plan.close()
