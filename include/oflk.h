@@ -275,13 +275,13 @@ int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, fl
 int oflk_plan_set_arithmetic(oflk_plan *plan, int mode);
 
 /* Which kernel runs a single-scale pass (oflk_plan_single_scale / _u8; results are the reference's either way).
- * The 5x5 window has a streaming kernel (no LDS; window sums vertical-then-horizontal), which equals np.sum's order exactly
+ * The 5x5 and 7x7 windows have a streaming kernel (no LDS; window sums vertical-then-horizontal), which equals np.sum's order exactly
  * wherever the frames are integers in [0, 255] -- what python/optical_flow_verifier.py:61-65 makes of the 8-bit files -- and a
  * window's sum Ix^2, sum Iy^2 stay below 2^16 (every partial sum is then exact in any order; proof in csrc/oflk_stream.hpp);
  * tiles where either is in doubt are flagged on the device and redone by the tile kernel in NumPy's order within the same call.
  * OFLK_KERNELS_AUTO (default): the streaming kernel for launches large enough to fill the chip with it (it walks rows serially
  * inside a wave: a single small pair is faster on the tile kernel), the tile kernel otherwise.  OFLK_KERNELS_TILE: the tile
- * kernel for everything (NumPy's order throughout).  OFLK_KERNELS_STREAM: the streaming kernel whenever the window is 5x5. */
+ * kernel for everything (NumPy's order throughout).  OFLK_KERNELS_STREAM: the streaming kernel whenever the window is 5x5 or 7x7. */
 #define OFLK_KERNELS_AUTO 0
 #define OFLK_KERNELS_TILE 1
 #define OFLK_KERNELS_STREAM 2

@@ -279,6 +279,12 @@ unsigned long long conv_threshold(double count)
     return hi;
 }
 
+// resident blocks of the redo pass after the streaming single-scale kernel: one per CU -- an empty list (the common case)
+// then costs 7 us instead of the 22 us of a full round of 1024 blocks, a long one is walked four times slower
+#ifndef OFLK_REDO_BLOCKS
+#define OFLK_REDO_BLOCKS 256
+#endif
+
 // u8: a.prev / a.curr point at uint8 frames (finest level of a uint8 plan); never with MODE_GRADS
 template <int MODE>
 int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_in, int B, bool u8 = false)
@@ -325,7 +331,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     if (MODE == MODE_SINGLE && a.redo_pass) {
         // redo pass of the streaming kernel: resident blocks that walk the device-side list of flagged tiles
         a.nseg = 0;
-        nblocks = (unsigned)std::min<long>((long)B * tiles_x * tiles_y, 1024);
+        nblocks = (unsigned)std::min<long>((long)B * tiles_x * tiles_y, OFLK_REDO_BLOCKS);
     } else if (cap <= 1) {
         a.nseg = 0;
         nblocks = (unsigned)(tiles_x * tiles_y * B);
@@ -375,6 +381,19 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
         if (vec) hipLaunchKernelGGL((k_lkw<HWV, MODE, true>), grid, dim3(256), 0, s, a);                  \
         else hipLaunchKernelGGL((k_lkw<HWV, MODE, false>), grid, dim3(256), 0, s, a);                     \
     } while (0)
+    if constexpr (MODE == MODE_SINGLE) {
+        if (a.redo_pass && hw == 3) {   // the 7x7 kernel's list-walking instantiation
+            if (u8) {
+                if (vec) hipLaunchKernelGGL((k_lkw<3, MODE_SINGLE, true, unsigned char, true>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((k_lkw<3, MODE_SINGLE, false, unsigned char, true>), grid, dim3(256), 0, s, a);
+            } else {
+                if (vec) hipLaunchKernelGGL((k_lkw<3, MODE_SINGLE, true, float, true>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((k_lkw<3, MODE_SINGLE, false, float, true>), grid, dim3(256), 0, s, a);
+            }
+            HIP_TRY(hipGetLastError());
+            return OFLK_OK;
+        }
+    }
     switch (hw) {
         case 1: OFLK_LAUNCH_LKW(1); break;
         case 2: OFLK_LAUNCH_LKW(2); break;
@@ -396,7 +415,7 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
 #define OFLK_LKS_SEG_ROWS 128
 #endif
 template <int MODE>
-int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int B, bool u8, int warp)
+int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int B, bool u8, int warp, int hw = 2)
 {
     LkArgs a = a_in;
     a.B = B;
@@ -440,6 +459,14 @@ int launch_lks(oflk_plan *plan, hipStream_t s, int cls, const LkArgs &a_in, int 
             }
         } else if (warp == WARP_LERP64) OFLK_LAUNCH_LKS(WARP_LERP64);
         else OFLK_LAUNCH_LKS(WARP_SCIPY);
+    } else if (hw == 3) {
+        if (u8) {
+            if (vec) hipLaunchKernelGGL((k_lks<MODE_SINGLE, true, WARP_SCIPY, unsigned char, false, 3>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_lks<MODE_SINGLE, false, WARP_SCIPY, unsigned char, false, 3>), grid, block, 0, s, a);
+        } else {
+            if (vec) hipLaunchKernelGGL((k_lks<MODE_SINGLE, true, WARP_SCIPY, float, false, 3>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_lks<MODE_SINGLE, false, WARP_SCIPY, float, false, 3>), grid, block, 0, s, a);
+        }
     } else {
         OFLK_LAUNCH_LKS(WARP_SCIPY);
     }
@@ -726,7 +753,7 @@ OFLK_API int oflk_plan_create(oflk_plan **out, int device, int B, int H, int W, 
         if (!rc && (iters > 0 || levels > 1)) rc = dmalloc(&p->flow[l], (size_t)2 * 2 * B * n, &p->ws_bytes);   // two interleaved slots
     }
     if (!rc) rc = dmalloc(&p->state, p->state_words() / 2, &p->ws_bytes);
-    if (!rc && p->hw == 2) {
+    if (!rc && (p->hw == 2 || p->hw == 3)) {
         // redo list of the single-scale streaming kernel (LkArgs::redo): all zero between calls
         const size_t n = 2 + 2 * (size_t)B * ((W + k5TX - 1) / k5TX) * ((H + k5TY - 1) / k5TY);
         rc = dmalloc(&p->redo, n, &p->ws_bytes);
@@ -765,13 +792,13 @@ int plan_single_scale(oflk_plan *p, const void *d_prev, const void *d_curr, bool
     // segments of ~40 rows is latency-bound there (one 640x480 pair: 37 us against the tile kernel's 6), so small launches
     // keep the tile kernel -- both are exact, the choice is speed only.
     const long stream_waves = ((long)p->W + kLksOutW - 1) / kLksOutW * p->B * std::max(1, p->H / 40);
-    if (p->hw == 2 && p->H > 4 && p->W > 4 &&
+    if ((p->hw == 2 || p->hw == 3) && p->H > 2 * p->hw && p->W > 2 * p->hw &&
         ((p->kernels == OFLK_KERNELS_AUTO && stream_waves >= 2048) || p->kernels == OFLK_KERNELS_STREAM)) {
         // 5x5 window: the streaming kernel, whose order-free sums are NumPy's wherever the frames are integers in [0, 255]
         // and a window's Sxx, Syy stay below 2^16 (proof at kLksExactBound); it flags the tiles where that is in doubt and
         // the tile kernel redoes exactly those in NumPy's order.  Results are the reference's either way.
         a.redo = p->redo;   // allocated and zeroed with the plan
-        int rc = launch_lks<MODE_SINGLE>(p, s, KC_LK_SINGLE, a, p->B, u8, WARP_SCIPY);
+        int rc = launch_lks<MODE_SINGLE>(p, s, KC_LK_SINGLE, a, p->B, u8, WARP_SCIPY, p->hw);
         if (rc) return rc;
         a.redo_pass = 1;
         return launch_lk<MODE_SINGLE>(p, s, KC_LK_REDO, p->hw, a, p->B, u8);

@@ -1020,7 +1020,9 @@ __device__ __forceinline__ void probe(const float *lds)
     }
 }
 
-template <int HW, int MODE, bool VEC, class PIX = float>
+// REDOL: the instantiation of a window without vertical chaining (7x7) that can walk the streaming kernel's redo list
+// (the 5x5 kernel walks it with its chaining loop); a separate instantiation, so that the ordinary 7x7 kernel keeps its registers
+template <int HW, int MODE, bool VEC, class PIX = float, bool REDOL = false>
 __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
 {
     static_assert(MODE != MODE_GRADS || sizeof(PIX) == 4, "gradient planes are float32");
@@ -1066,7 +1068,8 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     // and the carried rows would take (7x7: 153 -> 172 VGPRs, 3 -> 2 waves per SIMD)
     constexpr bool CHAIN = kLkChain<HW, MODE>;
     // the redo pass of k_lks (SINGLE, 5x5): the block walks its share of the list of flagged tiles, one tile per trip
-    constexpr bool CAN_REDO = MODE == MODE_SINGLE && HW == 2;
+    constexpr bool CAN_REDO = MODE == MODE_SINGLE && (HW == 2 || REDOL);
+    constexpr bool LOOPS = CHAIN || CAN_REDO;   // the tile loop below runs more than once
     const bool redo = CAN_REDO && a.redo_pass != 0;   // uniform
     int b, tile_x, tile_y_first, ntile;
     if (redo) {
@@ -1172,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
     bt[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
 
-    for (int it = 0; it < (CHAIN ? ntile : 1); it++) {
+    for (int it = 0; it < (LOOPS ? ntile : 1); it++) {
         // re-derived per tile behind an opaque move: otherwise every per-thread address of all
         // three stages is hoisted out of the loop and held in registers (occupancy 4 -> 2)
         int tid = threadIdx.x;
@@ -1611,7 +1614,7 @@ __global__ __launch_bounds__(256) void k_lkw(LkArgs a)
         }
         OFLK_STAMP(13);   // [13] solve, flow += d, stores, |d| reduction
         // stage 3 has read the planes (the next tile's staging overwrites them) and s_red is complete
-        if (MODE == MODE_ITER || (CHAIN && it + 1 < ntile)) __syncthreads();
+        if (MODE == MODE_ITER || (LOOPS && it + 1 < ntile)) __syncthreads();
         OFLK_STAMP(14);   // [14] barrier 4
         if (MODE == MODE_ITER && tid == 0) {
             blk_u += (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);

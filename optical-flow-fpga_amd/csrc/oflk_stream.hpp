@@ -91,12 +91,16 @@ constexpr float kLksExactBound = 65536.0f;
 #endif
 struct __attribute__((packed, aligned(8))) Flow2 { float u0, v0, u1, v1; };   // two adjacent {u, v} cells at an 8-byte aligned address
 
-template <int MODE, bool VEC, int WARPV, class PIX = float, bool UPS = false>
+// HW = 2 (5x5) everywhere; HW = 3 (7x7) for MODE_SINGLE only: there the order of the 49 additions does not matter on 8-bit
+// frames (same bound: sum |Ix It| <= sqrt(2^16 * 49 * 255^2) = 456 960 < 2^20), so the association of the sums below is free.
+template <int MODE, bool VEC, int WARPV, class PIX = float, bool UPS = false, int HW = 2>
 __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
 {
     static_assert(MODE == MODE_SINGLE || MODE == MODE_ITER, "gradient planes take the tile kernel");
     static_assert(!UPS || MODE == MODE_ITER, "the fused flow upsampling belongs to an iteration");
-    constexpr int HW = 2, R = HW + 1, HL = 2, OUTW = kLksOutW, WPB = 4;
+    static_assert(HW == 2 || (HW == 3 && MODE == MODE_SINGLE), "7x7 streams only where the summation order is provably irrelevant");
+    constexpr int R = HW + 1, HL = 2, OUTW = kLksOutW, WPB = 4;   // halo R = 3 or 4 columns: two lanes either side
+    constexpr int QR = 2 * HW - 1 == 3 ? 3 : 6;                  // period of the ring of vertical pair sums
     constexpr int SHR = 0x138, SHL = 0x130;   // DPP wave_shr:1 / wave_shl:1
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     // on: a wave holds LD rows of 16 - 28 bytes per lane
     constexpr int LD = MODE == MODE_SINGLE ? OFLK_LKS_LD_SINGLE : OFLK_LKS_LD_ITER;
     static_assert(LD % 3 == 0, "the load ring's period must be a multiple of the other rings' period");
+    constexpr int U = LD % QR == 0 ? LD : LD * QR / 3;   // unroll: lcm of the ring periods (LD and QR are multiples of 3)
     float2 Pr[LD];                        // prev rows
     float2 Qr[LD];                        // SINGLE: curr rows
     float4 Fr[LD];                        // ITER: flow rows
@@ -228,10 +233,11 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     // frame-average rows {lo, hi, left neighbour of lo, right neighbour of hi}, ring of three
     float Alo[3], Ahi[3], AL[3], AR[3];
     float2 it1 = make_float2(0.0f, 0.0f);                        // It of the row above
-    float P1[5][2], Qv[3][5][2];                                 // previous product row; ring of vertical pair sums
+    float P1[5][2], Qv[QR][5][2];                                // previous product row; ring of vertical pair sums
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        Alo[j] = Ahi[j] = AL[j] = AR[j] = 0.0f;
+    for (int j = 0; j < 3; j++) Alo[j] = Ahi[j] = AL[j] = AR[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < QR; j++) {
 #pragma unroll
         for (int pl = 0; pl < 5; pl++) Qv[j][pl][0] = Qv[j][pl][1] = 0.0f;
     }
@@ -312,11 +318,13 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
     for (int k = 0; k < LD; k++) issue_loads(k, r0 + k);
     issue_gathers(0, r0);
 
-    for (int i0 = 0; i0 < n_it; i0 += LD) {
-        static_for(std::make_integer_sequence<int, LD>{}, [&](auto jc) {
-            constexpr int jl = decltype(jc)::value;           // = i mod LD: slot of the load rings
-            constexpr int j = jl % 3;                         // = i mod 3: slot of the other rings
-            const int i = i0 + jl;   // (the last trip may run up to LD - 1 rows past the segment: clamped loads, no stores)
+    for (int i0 = 0; i0 < n_it; i0 += U) {
+        static_for(std::make_integer_sequence<int, U>{}, [&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            constexpr int jl = jj % LD;                       // = i mod LD: slot of the load rings
+            constexpr int j = jj % 3;                         // = i mod 3: slot of the frame-average ring
+            constexpr int jq = jj % QR;                       // = i mod QR: slot of the pair-sum ring
+            const int i = i0 + jj;   // (the last trip may run up to U - 1 rows past the segment: clamped loads, no stores)
             const int r = r0 + i;
             // ---- second frame of row r (warped if ITER), frame average, It --------------------------------
             float2 p = Pr[jl];
@@ -341,9 +349,9 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
                 if constexpr (sizeof(PIX) == 4) {
                     // a float32 frame is only promised to be what the verifier makes of 8-bit files (optical_flow_verifier.py:61-65);
                     // a pixel that is not an integer in [0, 255] voids the exactness argument for the windows it touches: the
-                    // outputs completed by this and the next six iterations, three columns either side
+                    // outputs completed by this and the next 2R iterations, R columns either side
                     auto integral = [](float t) { return t == __builtin_truncf(t) && fabsf(t - 127.5f) <= 127.5f; };
-                    if (!(integral(p.x) && integral(p.y) && integral(q.x) && integral(q.y))) hold = 7;
+                    if (!(integral(p.x) && integral(p.y) && integral(q.x) && integral(q.y))) hold = 2 * R + 1;
                 }
             }
             if constexpr (MODE == MODE_SINGLE) {
@@ -408,8 +416,13 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
 #pragma unroll
                 for (int pl = 0; pl < 5; pl++) {
                     // ring slot of the pair sum q[g'] = p[g'] + p[g'+1]: the iteration that formed it, mod 3
-                    V[pl][c] = (Qv[(j + 2) % 3][pl][c] + Qv[(j + 1) % 3][pl][c]) + pr[pl];   // (q[g-4] + q[g-2]) + p[g]
-                    Qv[(j + 2) % 3][pl][c] = P1[pl][c] + pr[pl];                              // q[g-1]
+                    if constexpr (HW == 2) {
+                        V[pl][c] = (Qv[(jq + 2) % 3][pl][c] + Qv[(jq + 1) % 3][pl][c]) + pr[pl];   // (q[g-4] + q[g-2]) + p[g]
+                        Qv[(jq + 2) % 3][pl][c] = P1[pl][c] + pr[pl];                              // q[g-1]
+                    } else {
+                        V[pl][c] = ((Qv[jq][pl][c] + Qv[(jq + 2) % 6][pl][c]) + Qv[(jq + 4) % 6][pl][c]) + pr[pl];   // ((q[g-6] + q[g-4]) + q[g-2]) + p[g]
+                        Qv[(jq + 5) % 6][pl][c] = P1[pl][c] + pr[pl];                                                // q[g-1]
+                    }
                     P1[pl][c] = pr[pl];
                 }
             }
@@ -419,10 +432,17 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
             for (int pl = 0; pl < 5; pl++) {
                 const float lo = V[pl][0], hi = V[pl][1];
                 const float pp = lo + hi;
-                const float X = wshift<SHR>(pp) + pp;          // (V[c-2] + V[c-1]) + (V[c] + V[c+1])
-                S[pl][0] = X + wshift<SHL>(lo);                // ... + V[c+2]
-                const float Y = wshift<SHR>(hi) + pp;          // V[c-2] + (V[c-1] + V[c])      (c = the odd column)
-                S[pl][1] = Y + wshift<SHL>(pp);                // ... + (V[c+1] + V[c+2])
+                if constexpr (HW == 2) {
+                    const float X = wshift<SHR>(pp) + pp;          // (V[c-2] + V[c-1]) + (V[c] + V[c+1])
+                    S[pl][0] = X + wshift<SHL>(lo);                // ... + V[c+2]
+                    const float Y = wshift<SHR>(hi) + pp;          // V[c-2] + (V[c-1] + V[c])      (c = the odd column)
+                    S[pl][1] = Y + wshift<SHL>(pp);                // ... + (V[c+1] + V[c+2])
+                } else {
+                    // seven columns: the three lane pairs around the lane plus one column two lanes away
+                    const float X = (wshift<SHR>(pp) + pp) + wshift<SHL>(pp);
+                    S[pl][0] = X + wshift<SHR>(wshift<SHR>(hi));   // even column c: ... + V[c-3]
+                    S[pl][1] = X + wshift<SHL>(wshift<SHL>(lo));   // odd column c:  ... + V[c+3]
+                }
                 if constexpr ((OFLK_LKS_ABL & 16) != 0) { S[pl][0] = lo; S[pl][1] = hi; }
             }
             const bool oky = o >= HW && o < H - HW;            // borders stay 0 (lucas_kanade_core.py:101-108)
@@ -490,11 +510,11 @@ __global__ __launch_bounds__(256) OFLK_LKS_ATTR void k_lks(LkArgs a)
             if constexpr (MODE == MODE_SINGLE) {
                 // at the last output row of a tile row and at the end of the segment the doubtful windows of the last rows go
                 // to the redo list (LkArgs::redo), tile by tile: the wave's columns reach at most four tile columns; a lane
-                // vouches for the columns three either side of its pair (a superset of the windows its pixels are in)
+                // vouches for the columns R either side of its pair (a superset of the windows its pixels are in)
                 if (a.redo != nullptr && o_live && (((o + 1) % k5TY) == 0 || o == ye - 1)) {
                     const int tiles_x = (W + k5TX - 1) / k5TX, tiles_y = (H + k5TY - 1) / k5TY;
-                    const int tlo = min(max(x - 3, 0), Wm1) / k5TX, thi = min(max(x + 4, 0), Wm1) / k5TX;
-                    const int t_first = min(max(xw - 3, 0), Wm1) / k5TX, t_last = min(max(xw + 131, 0), Wm1) / k5TX;
+                    const int tlo = min(max(x - R, 0), Wm1) / k5TX, thi = min(max(x + 1 + R, 0), Wm1) / k5TX;
+                    const int t_first = min(max(xw - R, 0), Wm1) / k5TX, t_last = min(max(xw + 128 + R, 0), Wm1) / k5TX;
                     const unsigned T = (unsigned)(a.B * tiles_y * tiles_x);
                     for (int t = t_first; t <= t_last; t++) {   // uniform bounds
                         if (__ballot(inexact != 0u && (tlo == t || thi == t)) != 0ull && lane == 0) {

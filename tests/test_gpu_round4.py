@@ -190,25 +190,26 @@ def _frames(kind, rng, H, W):
     return a, b
 
 
+@pytest.mark.parametrize("win", [5, 7])
 @pytest.mark.parametrize("shape", [(480, 640), (241, 323), (97, 130), (24, 64), (25, 121), (1080, 1920)])
 @pytest.mark.parametrize("kind", ["synth", "noise", "edges", "fractional", "speckled"])
-def test_single_scale_streaming_path_is_exact(oracle, shape, kind):
-    """oflk_plan_single_scale, 5x5, through the streaming kernel == the oracle value for value, for every kind of frame: the
-    doubtful tiles (bound exceeded, non-integral or out-of-range pixels) are redone in NumPy's order inside the call; the tile
-    kernel and the automatic choice give the same"""
+def test_single_scale_streaming_path_is_exact(oracle, shape, kind, win):
+    """oflk_plan_single_scale, 5x5 and 7x7, through the streaming kernel == the oracle value for value, for every kind of
+    frame: the doubtful tiles (bound exceeded, non-integral or out-of-range pixels) are redone in NumPy's order inside the
+    call; the tile kernel and the automatic choice give the same"""
     import _oflk
 
     H, W = shape
     rng = np.random.default_rng(7 * H + W)
     p, c = _frames(kind, rng, H, W)
-    ou, ov = oracle.lucas_kanade_single_scale(p, c, 5)
-    plan = _oflk.Plan(0, 2, H, W, 1, 5, 0)
+    ou, ov = oracle.lucas_kanade_single_scale(p, c, win)
+    plan = _oflk.Plan(0, 2, H, W, 1, win, 0)
     pp, cc = np.stack([p, c]), np.stack([c, p])        # two pairs per call (the second one reversed)
     for choice in (2, 1, 0, 2):   # streaming kernel forced, tile kernel, automatic (by launch size), streaming again
         plan.set_kernels(choice)
         u, v = _single(plan, pp, cc)
-        assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), (shape, kind, choice)
-    ru, rv = oracle.lucas_kanade_single_scale(c, p, 5)
+        assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), (shape, kind, choice, win)
+    ru, rv = oracle.lucas_kanade_single_scale(c, p, win)
     assert np.array_equal(u[1], ru) and np.array_equal(v[1], rv)
     if kind in ("synth", "noise", "edges"):
         u8, v8 = _single(plan, pp.astype(np.uint8), cc.astype(np.uint8), u8=True)
@@ -222,17 +223,18 @@ def test_single_scale_bound_of_the_exactness_argument(oracle):
     import _oflk
 
     H, W = 96, 192
-    for h in (150, 160, 161, 162, 163, 170, 255):
-        a = np.zeros((H, W), np.float32)
-        a[:, W // 2:] = h
-        a[H // 2:, : W // 4] = h
-        b = np.roll(a, (1, 1), axis=(0, 1))
-        ou, ov = oracle.lucas_kanade_single_scale(a, b, 5)
-        plan = _oflk.Plan(0, 1, H, W, 1, 5, 0)
-        plan.set_kernels(2)
-        u, v = _single(plan, a[None], b[None])
-        assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), h
-        plan.close()
+    for win in (5, 7):
+        for h in (130, 136, 137, 138, 150, 160, 161, 162, 163, 170, 255):   # 7x7: Sxx = 3.5 h^2 crosses 2^16 at h = 136.8
+            a = np.zeros((H, W), np.float32)
+            a[:, W // 2:] = h
+            a[H // 2:, : W // 4] = h
+            b = np.roll(a, (1, 1), axis=(0, 1))
+            ou, ov = oracle.lucas_kanade_single_scale(a, b, win)
+            plan = _oflk.Plan(0, 1, H, W, 1, win, 0)
+            plan.set_kernels(2)
+            u, v = _single(plan, a[None], b[None])
+            assert np.array_equal(u[0], ou) and np.array_equal(v[0], ov), (win, h)
+            plan.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -204,7 +204,8 @@ def stream_main(cases, seed):
                     b[int(rng.integers(0, H)), int(rng.integers(0, W))] = np.float32(rng.choice([17.75, -0.5, 256.0]))
             prs.append((a, b))
         prev, curr = np.stack([p for p, _ in prs]), np.stack([c for _, c in prs])
-        plan = _oflk.Plan(0, B, H, W, 1, 5, 0)
+        win = int(rng.choice([4, 5, 5, 6, 7, 7]))
+        plan = _oflk.Plan(0, B, H, W, 1, win, 0)
         plan.set_kernels(2)
         tp, tc = torch.from_numpy(prev).to(dev), torch.from_numpy(curr).to(dev)
         u, v = torch.empty_like(tp), torch.empty_like(tp)
@@ -213,7 +214,7 @@ def stream_main(cases, seed):
         hu, hv = u.cpu().numpy(), v.cpu().numpy()
         ok = True
         for b_, (a, b) in enumerate(prs):
-            ou, ov = O.lucas_kanade_single_scale(a, b, 5)
+            ou, ov = O.lucas_kanade_single_scale(a, b, win)
             ok &= same(hu[b_], ou) and same(hv[b_], ov)
         if kind in (0, 1):
             t8p, t8c = tp.to(torch.uint8), tc.to(torch.uint8)   # (kept alive until the kernels have run)
@@ -223,7 +224,7 @@ def stream_main(cases, seed):
         plan.close()
         if not ok:
             bad += 1
-            print(f"MISMATCH stream case {i}: B={B} H={H} W={W} kind={kind}", flush=True)
+            print(f"MISMATCH stream case {i}: B={B} H={H} W={W} kind={kind} win={win}", flush=True)
         if i % 50 == 49:
             print(f"{i + 1} stream cases, {bad} mismatches", flush=True)
     print(f"done: {cases} stream cases, {bad} mismatches")

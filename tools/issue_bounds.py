@@ -132,8 +132,8 @@ def main():
         for key, sub, match, sym, waves, bpp in (
                 ("single_tile_5x5", "tile5", "k_lkw<2, 0, true", "_ZN4oflk5k_lkwILi2ELi0ELb1EfEEvNS_6LkArgsE", 4, 16),
                 ("single_tile_7x7", "tile7", "k_lkw<3, 0, true", "_ZN4oflk5k_lkwILi3ELi0ELb1EfEEvNS_6LkArgsE", 3, 16),
-                ("single_stream_5x5", "stream5", "k_lks<0, true", "_ZN4oflk5k_lksILi0ELb1ELi0EfLb0EEEvNS_6LkArgsE", 4, 16),
-                ("iter_stream_5x5_tolerant", "tol", "k_lks<1, true, 1, float, false", "_ZN4oflk5k_lksILi1ELb1ELi1EfLb0EEEvNS_6LkArgsE", 2, 24)):
+                ("single_stream_5x5", "stream5", "k_lks<0, true", "_ZN4oflk5k_lksILi0ELb1ELi0EfLb0ELi2EEEvNS_6LkArgsE", 4, 16),
+                ("iter_stream_5x5_tolerant", "tol", "k_lks<1, true, 1, float, false, 2", "_ZN4oflk5k_lksILi1ELb1ELi1EfLb0ELi2EEEvNS_6LkArgsE", 2, 24)):
             try:
                 r = kernel_bounds(single_dir + "/" + sub, match, sym, asm, prices, waves_per_simd=waves)
                 r["hbm_floor_us"] = round(px * bpp / 8e12 * 1e6, 1)

@@ -79,6 +79,7 @@ def main():
     run("configs[2] batched x32, uint8 frames", 32, 1080, 1920, 3, 5, 3, 20, "u8")
     run("configs[4]: 7680x4320 pair, 7x7 window, fp16 gradients/accumulators (single-scale)", 1, 4320, 7680, 1, 7, 0, 20, "fp16")
     run("configs[4] geometry, exact fp32 arithmetic for comparison", 1, 4320, 7680, 1, 7, 0, 20)
+    run("configs[4] geometry, exact fp32 arithmetic, tile kernel throughout (rounds 1-3)", 1, 4320, 7680, 1, 7, 0, 20, "tile")
     run("configs[4] geometry, 3-level pyramidal 7x7 x3, exact fp32", 1, 4320, 7680, 3, 7, 3, 10)
     # the RTL-bit-accurate integer mode, the RTL's own frame size
     for B, H, W, reps in ((1, 240, 320, 200), (256, 240, 320, 20), (64, 512, 1024, 20)):
