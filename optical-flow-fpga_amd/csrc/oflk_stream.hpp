@@ -1,11 +1,12 @@
-// oflk_stream.hpp -- k_lks: the streaming form of the fused Lucas-Kanade kernel (5x5 window), gfx950.
+// oflk_stream.hpp -- k_lks: the streaming form of the fused Lucas-Kanade kernel (5x5 window; 7x7 single-scale), gfx950.
 //
 // k_lkw (oflk_kernels.hpp) stages tiles in LDS because NumPy's summation order of a 5x5 window
 // (lucas_kanade_core.py:115-119) has no separable form.  Where the order of the 25 additions is free, the window
-// sums separate -- five rows added vertically, five columns horizontally -- and the kernel can STREAM: no LDS, no
+// sums separate -- five rows added vertically, five columns horizontally -- and the kernel can STREAM: no LDS tile, no
 // barrier.  A wave owns a strip of 128 image columns, two per lane, and walks down a segment of rows:
-//   per row   coalesced loads of prev and the flow (three rows ahead); the bilinear gathers of `curr` for the row
-//             after this one are issued before this row's arithmetic and used after it
+//   per row   coalesced loads of prev and the flow (three rows ahead) and a coalesced read of `curr` that brings the lines
+//             the warp will gather from into the L2; the bilinear gathers of `curr` for the row after this one are issued
+//             before this row's arithmetic and used after it
 //             warp (ITER), frame average, It; Sobel/8 of the row above in convolve2d's own tap order, from three
 //             average rows held in registers, the x-neighbours through DPP wave shifts (the gradients are the
 //             reference's, bit for bit)
@@ -13,20 +14,25 @@
 //             and plane from a ring of pair sums; horizontal 5-sums by four wave shifts per plane:
 //                 even column c:  ((V[c-2] + V[c-1]) + (V[c] + V[c+1])) + V[c+2]
 //                 odd column c:   (V[c-2] + (V[c-1] + V[c])) + (V[c+1] + V[c+2])
-//             2x2 solve in the reference's operation sequence (IEEE division), flow += d, |d| sums
+//             2x2 solve in the reference's operation sequence (IEEE division), flow += d (the flow of the output row comes
+//             back from a per-wave LDS ring of the last eight flow rows: same lane writes and reads), |d| sums
 // A wave produces 120 of its 128 columns (window halo 2 + Sobel halo 1, rounded to lane pairs); a segment of Hs
-// rows costs 6 extra rows.
+// rows costs 6 extra rows.  Three things decide its speed, all found in the ISA: wide loads must stay
+// whole (selects on a loaded value sit where it is USED), loads are issued oldest-needed first because results return in
+// issue order, and the unrolled row body has no early exit, so that the compiler's wait counts leave the younger loads in
+// flight.
 //
-// Two uses:
-//  * OFLK_ARITH_TOLERANT (opt-in): the iterations of the two finest pyramid levels.  The sums are NOT in NumPy's
+// Uses:
+//  * OFLK_ARITH_TOLERANT (opt-in): the iterations of the two finest pyramid levels; with UPS the first iteration of a level
+//    also upsamples the coarser level's flow on the fly (upsample_flow in the fused-lerp form).  The sums are NOT in NumPy's
 //    order, so flows are close to, not equal to, the reference's: oracle/oflk_tolerant_model.c states this arithmetic
 //    on the CPU, tests hold this kernel to it bit for bit and the model to the reference-made dense flows within
 //    the 1e-4 bar (tools/experiments/fast_mode_ablation.py: what each cell of the pass costs).
-//  * MODE_SINGLE on integer-valued frames (EXACT): gradients are multiples of 1/16 there, products of 2^-8 (2^-4
-//    with It), so while a window's sums stay below 2^16 every partial sum is exact in any order and the separable
+//  * MODE_SINGLE on integer-valued frames (EXACT; 5x5 and, HW = 3, 7x7): gradients are multiples of 1/16 there, products of
+//    2^-8 (2^-4 with It), so while a window's sums stay below 2^16 every partial sum is exact in any order and the separable
 //    sums ARE NumPy's (proof at kLksExactBound).  A wave checks Sxx, Syy < 2^16 on every window it solves -- and, for
-//    float32 frames, that every pixel it loads is an integer in [0, 255] -- and flags the 64 x 24 tiles where that fails;
-//    the tile kernel k_lkw then redoes exactly those tiles in NumPy's order (k_lkw's `redo` flags).
+//    float32 frames, that every pixel it loads is an integer in [0, 255] -- and lists the 64 x 24 tiles where that fails;
+//    the tile kernel k_lkw then redoes exactly those tiles in NumPy's order (LkArgs::redo).
 #pragma once
 
 namespace oflk {
@@ -71,6 +77,7 @@ constexpr int kLksOutW = 120;   // output columns per wave
 //   every partial sum of the non-negative terms of Sxx (Syy) is <= Sxx (Syy) < 2^16 = 2^24 * 2^-8                  -> exact
 //   every partial sum of Sxy is bounded by sum |Ix Iy| <= (Sxx + Syy) / 2 < 2^16                                    -> exact
 //   every partial sum of Sxt by sum |Ix It| <= sqrt(Sxx * sum It^2) <= sqrt(2^16 * 25 * 255^2) = 326 400 < 2^20 = 2^24 * 2^-4 -> exact
+//                               (7x7: sqrt(2^16 * 49 * 255^2) = 456 960 < 2^20)
 // so the five sums are the exact real numbers in ANY order of additions, hence equal to np.sum's; the solve that follows
 // is the reference's operation sequence on equal inputs.  A window that fails the bound (or a pixel that is not such an
 // integer) flags its tile for the NumPy-order kernel.
