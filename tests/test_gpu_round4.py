@@ -412,3 +412,54 @@ def test_tolerant_mode_keeps_the_exit_decision_band_and_its_exact_redo(oracle):
     mu, mv, _, mruns = M.pyramidal(prev, c, M.tolerant_spec(L, K, (H, W)), 5)
     assert list(runs) == list(mruns) and np.array_equal(u.cpu().numpy()[0], mu) and np.array_equal(v.cpu().numpy()[0], mv)
     plan.close()
+
+
+def test_round4_passes_captured_into_a_hip_graph(oracle):
+    """the new passes only enqueue kernels too: a tolerant pyramidal pass and a single-scale pass with the streaming kernel
+    forced (streaming launch + redo pass over a device-side list), captured on a side stream and replayed on new frames
+    written into the same buffers, give the model's / the oracle's flow on every replay"""
+    import torch
+
+    import _oflk
+    import oflk_tolerant_model as M
+    from oflk_synth import synth_pair
+
+    dev = torch.device("cuda", 0)
+    H, W, L, K = 240, 320, 3, 3
+    prev = torch.empty((2, H, W), dtype=torch.float32, device=dev)
+    curr = torch.empty_like(prev)
+    u, v = torch.empty_like(prev), torch.empty_like(prev)
+    us, vs = torch.empty_like(prev), torch.empty_like(prev)
+    plan = _oflk.Plan(0, 2, H, W, L, 5, K)
+    plan.set_arithmetic(2)
+    plan_s = _oflk.Plan(0, 2, H, W, 1, 5, 0)
+    plan_s.set_kernels(2)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), st)   # warm-up outside the capture
+    plan_s.single_scale(prev.data_ptr(), curr.data_ptr(), us.data_ptr(), vs.data_ptr(), st)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        s_ = torch.cuda.current_stream().cuda_stream
+        plan.pyramidal(prev.data_ptr(), curr.data_ptr(), u.data_ptr(), v.data_ptr(), s_)
+        plan_s.single_scale(prev.data_ptr(), curr.data_ptr(), us.data_ptr(), vs.data_ptr(), s_)
+    for rep in range(3):
+        pairs = [synth_pair(H, W, pair_index=50 + 2 * rep + b) for b in range(2)]
+        if rep == 1:   # a frame with 0 / 255 blocks: the redo list is not empty on this replay
+            a = pairs[0][0].copy()
+            a[40:80, 60:140] = 255.0 * ((np.add.outer(np.arange(40), np.arange(80)) // 3) % 2)
+            pairs[0] = (a.astype(np.float32), pairs[0][1])
+        prev.copy_(torch.from_numpy(np.stack([p for p, _ in pairs])))
+        curr.copy_(torch.from_numpy(np.stack([c for _, c in pairs])))
+        for t in (u, v, us, vs):
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for b, (p, c) in enumerate(pairs):
+            mu, mv, _, _ = M.pyramidal(p, c, M.tolerant_spec(L, K, (H, W)), 5)
+            assert np.array_equal(u[b].cpu().numpy(), mu) and np.array_equal(v[b].cpu().numpy(), mv), f"replay {rep} pair {b} (tolerant)"
+            ou, ov = oracle.lucas_kanade_single_scale(p, c, 5)
+            assert np.array_equal(us[b].cpu().numpy(), ou) and np.array_equal(vs[b].cpu().numpy(), ov), f"replay {rep} pair {b} (single)"
+    plan.close()
+    plan_s.close()
