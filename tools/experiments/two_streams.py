@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment: does running a batch as two half-batches on two streams (independent frame pairs, so no
 dependency between the halves) hide the ramp / tail of the 15 launches of a pyramidal call?
-Usage on the GPU box: python3 tools/experiments/two_streams.py"""
+Usage on the GPU box: python3 tools/experiments/two_streams.py [arith: 0 exact | 2 tolerant] [pairs]"""
 import sys
 from pathlib import Path
 
@@ -16,7 +16,8 @@ def main():
     from oflk_synth import synth_pair
 
     dev = torch.device("cuda", 0)
-    B, H, W = 32, 1080, 1920
+    arith = int(sys.argv[1]) if len(sys.argv) > 1 else 0     # 0 exact, 2 tolerant
+    B, H, W = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 1080, 1920
     host = [synth_pair(H, W, i) for i in range(4)]
     prev = torch.stack([torch.from_numpy(host[b % 4][0]) for b in range(B)]).to(dev)
     curr = torch.stack([torch.from_numpy(host[b % 4][1]) for b in range(B)]).to(dev)
@@ -25,6 +26,8 @@ def main():
     for nsplit in (1, 2, 4, 1, 2, 4):
         Bs = B // nsplit
         plans = [_oflk.Plan(0, Bs, H, W, 3, 5, 3) for _ in range(nsplit)]
+        for pl in plans:
+            pl.set_arithmetic(arith)
         streams = [torch.cuda.Stream() for _ in range(nsplit)]
 
         def step():
@@ -42,7 +45,7 @@ def main():
             step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
-        print(f"{nsplit} stream(s) x {Bs} pairs: {dt * 1e6:.0f} us per 32-pair step, {B * H * W / dt / 1e6:.0f} Mpix/s", flush=True)
+        print(f"arith {arith}: {nsplit} stream(s) x {Bs} pairs: {dt * 1e6:.0f} us per {B}-pair step, {B * H * W / dt / 1e6:.0f} Mpix/s", flush=True)
         for pl in plans:
             pl.close()
 
