@@ -243,7 +243,7 @@ int oflk_last_resolved(void);
  * visualize_pyramid_level at python/lucas_kanade_pyramidal.py:226.  Synchronises. */
 int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, float *v, void *stream);
 
-/* Arithmetic of the plan's fp64 stages.  OFLK_ARITH_EXACT (the default, and what every host entry point uses): SciPy's
+/* Arithmetic of the plan's fp64 stages.  OFLK_ARITH_EXACT (the default of plans and of the host entry points): SciPy's
  * operation sequence, every operation rounded on its own -- results equal the reference's value for value.
  * OFLK_ARITH_CONTRACTED (opt-in): the Gaussian pyramid (python/lucas_kanade_pyramidal.py:46-59) accumulates with fused
  * multiply-adds, 17 instead of 25 fp64 operations per blurred value on a kernel the fp64 pipe binds.  Intermediates
@@ -273,6 +273,11 @@ int oflk_plan_read_level_flow(oflk_plan *plan, int level, int pair, float *u, fl
 #define OFLK_ARITH_CONTRACTED 1
 #define OFLK_ARITH_TOLERANT 2
 int oflk_plan_set_arithmetic(oflk_plan *plan, int mode);
+/* The same choice for the host-pointer entry points (oflk_pyramidal*, oflk_pyramidal_u8*, the *_multi forms): process-wide,
+ * default OFLK_ARITH_EXACT.  The Python shims call it once when the environment variable OFLK_ARITH is set to "contracted" or
+ * "tolerant"; without it the drop-in functions return the reference's values.  Pairs whose exit decision is flagged are
+ * redone exactly in every mode (oflk_last_resolved). */
+int oflk_set_host_arithmetic(int mode);
 
 /* Which kernel runs a single-scale pass (oflk_plan_single_scale / _u8; results are the reference's either way).
  * The 5x5 and 7x7 windows have a streaming kernel (no LDS; window sums vertical-then-horizontal), which equals np.sum's order exactly

@@ -53,6 +53,7 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 std::atomic<int> g_device{0};   // device of the host-pointer entry points (oflk_set_device)
+std::atomic<int> g_host_arith{OFLK_ARITH_EXACT};   // arithmetic of the host-pointer entry points (oflk_set_host_arithmetic)
 std::atomic<int> g_multi_workers{0};   // oflk_multi_rehearsal: queue workers of the *_multi entry points (0 = one per device)
 
 int ensure_device(int dev)
@@ -1303,6 +1304,14 @@ OFLK_API int oflk_plan_set_arithmetic(oflk_plan *p, int mode)
     return OFLK_OK;
 }
 
+OFLK_API int oflk_set_host_arithmetic(int mode)
+{
+    if (mode != OFLK_ARITH_EXACT && mode != OFLK_ARITH_CONTRACTED && mode != OFLK_ARITH_TOLERANT)
+        return fail(OFLK_ERR_INVALID, "arithmetic mode must be OFLK_ARITH_EXACT (0), OFLK_ARITH_CONTRACTED (1) or OFLK_ARITH_TOLERANT (2), got %d", mode);
+    g_host_arith.store(mode);
+    return OFLK_OK;
+}
+
 OFLK_API int oflk_multi_rehearsal(int workers)
 {
     if (workers < 0 || workers > 64) return fail(OFLK_ERR_INVALID, "workers must be 0 ... 64, got %d", workers);
@@ -1419,6 +1428,7 @@ int host_plan(HostCtx &c, int dev, int B, int H, int W, int L, int win, int K, o
         if (q->B == B && q->H == H && q->W == W && q->L == L && q->win == win && q->K == K) {
             c.plans.erase(c.plans.begin() + (long)i);
             c.plans.insert(c.plans.begin(), q);
+            q->arith = g_host_arith.load();
             *out = q;
             return OFLK_OK;
         }
@@ -1432,6 +1442,7 @@ int host_plan(HostCtx &c, int dev, int B, int H, int W, int L, int win, int K, o
         rc = oflk_plan_create(&q, dev, B, H, W, L, win, K);
     }
     if (rc) return rc;
+    q->arith = g_host_arith.load();
     c.plans.insert(c.plans.begin(), q);
     while (c.plans.size() > kPlanCache) {
         plan_free(c.plans.back());

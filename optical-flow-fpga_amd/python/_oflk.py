@@ -77,6 +77,7 @@ SIGNATURES = {
     "oflk_plan_set_arithmetic": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_plan_set_kernels": (ctypes.c_int, [_vp, ctypes.c_int]),
     "oflk_multi_rehearsal": (ctypes.c_int, [ctypes.c_int]),
+    "oflk_set_host_arithmetic": (ctypes.c_int, [ctypes.c_int]),
     "oflk_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _vp]),
     "oflk_flow_metrics": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "oflk_plan_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
@@ -107,6 +108,12 @@ def lib() -> ctypes.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        # opt-in arithmetic of the host entry points (default: the reference's values): OFLK_ARITH=contracted | tolerant
+        mode = {"": 0, "exact": 0, "contracted": 1, "tolerant": 2}.get(os.environ.get("OFLK_ARITH", "").strip().lower())
+        if mode is None:
+            raise ValueError(f"OFLK_ARITH={os.environ['OFLK_ARITH']!r}: expected exact, contracted or tolerant")
+        if mode:
+            check(L.oflk_set_host_arithmetic(mode))
     return _lib
 
 

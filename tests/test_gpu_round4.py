@@ -463,3 +463,35 @@ def test_round4_passes_captured_into_a_hip_graph(oracle):
             assert np.array_equal(us[b].cpu().numpy(), ou) and np.array_equal(vs[b].cpu().numpy(), ov), f"replay {rep} pair {b} (single)"
     plan.close()
     plan_s.close()
+
+
+def test_host_entry_points_in_the_tolerant_mode(golden_dir):
+    """oflk_set_host_arithmetic(OFLK_ARITH_TOLERANT) (what OFLK_ARITH=tolerant makes the shims call): the drop-in function
+    then returns the tolerant model's flow -- within 1e-4 px of the reference's dense flow; switching back restores the
+    reference's digests"""
+    import hashlib
+
+    import _oflk
+    import lucas_kanade_pyramidal as P
+    import oflk_tolerant_model as M
+
+    L_ = _oflk.lib()
+    dense = np.load(golden_dir / "dense_reference_flows.npz")
+    z = np.load(golden_dir / "patterns_320x240.npz")
+    ref = json.loads((golden_dir / "reference_13patterns.json").read_text())["patterns"]
+    f0 = z["frame_0"].astype(np.float32)
+    try:
+        _oflk.check(L_.oflk_set_host_arithmetic(2))
+        for n in ("translate_medium", "rotate_small", "translate_extreme", "no_motion"):
+            f1 = z[f"frame_1__{n}"].astype(np.float32)
+            u, v = P.lucas_kanade_pyramidal(f0, f1, 3, 5, 3)
+            mu, mv, _, _ = M.pyramidal(f0, f1, M.tolerant_spec(3, 3, f0.shape), 5)
+            assert np.array_equal(u, mu) and np.array_equal(v, mv), n
+            assert _epe(u, v, dense[f"{n}__u"], dense[f"{n}__v"]) <= TOL, n
+    finally:
+        _oflk.check(L_.oflk_set_host_arithmetic(0))
+    f1 = z["frame_1__translate_medium"].astype(np.float32)
+    u, v = P.lucas_kanade_pyramidal(f0, f1, 3, 5, 3)
+    dig = lambda a: hashlib.sha256((np.ascontiguousarray(a, np.float32) + np.float32(0.0)).tobytes()).hexdigest()  # noqa: E731
+    assert dig(u) == ref["translate_medium"]["pyramidal"]["u_sha256"] and dig(v) == ref["translate_medium"]["pyramidal"]["v_sha256"]
+    assert L_.oflk_set_host_arithmetic(7) != 0
