@@ -85,3 +85,29 @@ def test_the_measure_catches_a_relaxation_that_is_over_the_bar(dense, patterns):
     p, c = patterns["translate_extreme"]
     u, v, _, _ = M.pyramidal(p, c, s, 5)
     assert _epe(u, v, dense["translate_extreme__u"], dense["translate_extreme__v"]) > TOL
+
+
+@pytest.mark.parametrize("key", ["e1", "e2", "e3", "m1", "m5"])
+def test_tolerant_arithmetic_on_the_reference_made_mid_size_cases(oracle, golden_dir, key):
+    """the 5x5 cases of tests/golden/reference_fullsize.json -- identical frames and sub-pixel motions whose levels leave their
+    loops after [1,1,1], [2,1,1] and [3,4,4] of 4 iterations, a 4-level / 5-iteration case, an odd 481x643 shape: the oracle
+    reproduces the reference's digests there (tests/test_oracle_golden.py), so its flow IS the reference's; the tolerant
+    arithmetic must take the same iteration counts and stay within 1e-4 px of it"""
+    import hashlib
+    import json
+
+    import oflk_tolerant_model as M
+    from oflk_synth import synth_pair, synth_pair_smooth
+
+    c = json.loads((golden_dir / "reference_fullsize.json").read_text())[key]
+    assert c["window_size"] == 5 and c["mode"] == "pyramidal"
+    h, w = c["shape"]
+    gen = synth_pair_smooth if c.get("smooth") else synth_pair
+    p, q = gen(h, w, c.get("pair_index", 0), c.get("dx", 3.0), c.get("dy", -1.5))
+    L, K = c["levels"], c["iterations"]
+    ou, ov, _, oruns = oracle.lucas_kanade_pyramidal_ex(p, q, L, 5, K)
+    dig = lambda a: hashlib.sha256((np.ascontiguousarray(a, np.float32) + np.float32(0.0)).tobytes()).hexdigest()  # noqa: E731
+    assert dig(ou) == c["u_sha256"] and dig(ov) == c["v_sha256"]          # the oracle's flow is the reference's
+    u, v, _, runs = M.pyramidal(p, q, M.tolerant_spec(L, K, (h, w)), 5)
+    assert list(runs) == list(oruns), (key, list(runs), list(oruns))
+    assert _epe(u, v, ou, ov) <= TOL, key
