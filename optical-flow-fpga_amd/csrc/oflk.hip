@@ -408,10 +408,11 @@ int launch_lk(oflk_plan *plan, hipStream_t s, int cls, int hw, const LkArgs &a_i
     return OFLK_OK;
 }
 
-// k_lks (oflk_stream.hpp): the streaming form of the 5x5 kernel, for passes whose window sums need not be in NumPy's
-// order (the tolerant mode's fine levels; single-scale on integer-valued frames, where any order is exact).  One wave
-// per (strip of 120 output columns, segment of Hs rows); segments are sized so that the launch is a whole number of
-// rounds of the chip's wave slots at the kernel's occupancy, ~64 rows or more each (a segment pays 6 extra rows).
+// k_lks (oflk_stream.hpp): the streaming form of the 5x5 kernel (single-scale: 7x7 too), for passes whose window sums need
+// not be in NumPy's order (the tolerant mode's fine levels; single-scale on integer-valued frames, where any order is
+// exact).  One wave per (strip of 120 output columns, segment of Hs rows); segments are sized so that the launch is a whole
+// number of rounds of the chip's wave slots at the kernel's occupancy, ~128 rows each when there are rounds to spare (a
+// segment pays 2 (hw + 1) extra rows), shorter ones when the launch would otherwise leave wave slots empty.
 #ifndef OFLK_LKS_SEG_ROWS
 #define OFLK_LKS_SEG_ROWS 128
 #endif
