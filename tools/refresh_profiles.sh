@@ -38,7 +38,9 @@ for k in ("fetch", "write"):
 PY
 bash tools/pmc_sq.sh $TAG > gpurun_out/sq_$TAG.log 2>&1
 cp gpurun_out/pmc_$TAG/summary.txt profiles/${TAG}_sq_counters.txt
-# 5. instruction-side bounds of the dominant kernel (needs the ISA: make asm) -> profiles/<tag>_issue_bounds.json
+# 5. instruction-side bounds of the dominant kernel -> profiles/<tag>_issue_bounds.json.  The ISA it prices is regenerated here
+#    from the sources of the library being measured (a stale oflk_gfx950.s once outlived the .so it described)
+make -C optical-flow-fpga_amd/csrc asm > gpurun_out/asm_$TAG.log 2>&1 || true
 # (vector-ALU cycles per instruction checked against wall-clock, with a census of where the waves ran)
 [ -x tools/ubench/valu_wall ] && timeout -k 10 300 ./tools/ubench/valu_wall > profiles/${TAG}_valu_wall.txt 2>&1 || true
 python3 tools/issue_bounds.py gpurun_out/pmc_$TAG profiles/${TAG}_valu_wall.txt profiles/${TAG}_issue_bounds.json > gpurun_out/issue_$TAG.log 2>&1 || cat gpurun_out/issue_$TAG.log
